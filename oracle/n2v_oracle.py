@@ -1,0 +1,251 @@
+"""ORACLE — test infrastructure, not product code.
+
+A CPU restatement (pure Python + numpy, no networkx) of the reference's walk
+path, row for row.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it; the product package under
+``node2vec-by-ecc_amd/`` never does.
+
+Pinned: every function below is checked bit-for-bit against the golden
+vectors in ``tests/golden/*.npz`` that ``tests/golden/make_golden.py``
+captured from the reference's own ``src/node2vec.py`` (see
+``tests/test_oracle_golden.py``).
+
+Reference citations are relative to /root/reference/.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------- graph
+class OracleGraph:
+    """Adjacency in networkx's dict-of-dict form with networkx's ordering rules.
+
+    ``adj[u][v] = weight``; ``nodes`` is insertion order (what ``list(G.nodes())``
+    returns, src/node2vec.py:88).  Construction mirrors src/main.py:66-80: a DiGraph
+    filled in file order (duplicate lines: last weight wins), then ``to_undirected``.
+    """
+
+    def __init__(self, edges, weights=None, directed=False):
+        succ = {}
+        for i, (u, v) in enumerate(edges):
+            u, v = int(u), int(v)
+            w = 1 if weights is None else weights[i]
+            if u not in succ:
+                succ[u] = {}
+            if v not in succ:
+                succ[v] = {}
+            succ[u][v] = w
+        self.directed = bool(directed)
+        if directed:
+            self.adj = succ
+        else:
+            # networkx DiGraph.to_undirected(): nodes first (same order), then every
+            # (u, v, d) in successor-adjacency order; later assignments overwrite.
+            und = {u: {} for u in succ}
+            for u, nbrs in succ.items():
+                for v, w in nbrs.items():
+                    und[u][v] = w
+                    und[v][u] = w
+            self.adj = und
+        self.nodes = list(self.adj.keys())
+
+    def neighbors(self, v):
+        return self.adj[v].keys()
+
+    def has_edge(self, u, v):
+        return u in self.adj and v in self.adj[u]
+
+    def edges(self):
+        """Order of networkx ``G.edges()`` (directed: all; undirected: each pair once)."""
+        if self.directed:
+            for u, nbrs in self.adj.items():
+                for v in nbrs:
+                    yield (u, v)
+        else:
+            seen = set()
+            for u, nbrs in self.adj.items():
+                for v in nbrs:
+                    if v not in seen:
+                        yield (u, v)
+                seen.add(u)
+
+
+# --------------------------------------------------------------------------- alias method
+def alias_setup(probs):
+    """src/node2vec.py:240-269 — Vose alias table with the reference's stack order."""
+    K = len(probs)
+    q = np.zeros(K)
+    J = np.zeros(K, dtype=np.int64)
+    smaller, larger = [], []
+    for kk, prob in enumerate(probs):
+        q[kk] = K * prob
+        if q[kk] < 1.0:
+            smaller.append(kk)
+        else:
+            larger.append(kk)
+    while len(smaller) > 0 and len(larger) > 0:
+        small = smaller.pop()
+        large = larger.pop()
+        J[small] = large
+        q[large] = q[large] + q[small] - 1.0
+        if q[large] < 1.0:
+            smaller.append(large)
+        else:
+            larger.append(large)
+    return J, q
+
+
+def alias_draw_u(J, q, u1, u2):
+    """src/node2vec.py:271-281 with the two uniforms passed in (both always consumed)."""
+    K = len(J)
+    kk = int(np.floor(u1 * K))
+    if u2 < q[kk]:
+        return kk
+    return int(J[kk])
+
+
+class Node2VecOracle:
+    """src/node2vec.py:5-204 (``popwalk == "none"`` only)."""
+
+    def __init__(self, G, is_directed, p, q):
+        self.G = G
+        self.is_directed = is_directed
+        self.p = p
+        self.q = q
+        self.alias_nodes = None
+        self.alias_edges = None
+
+    # src/node2vec.py:184-188 (also :13-25)
+    def get_alias_node(self, node):
+        G = self.G
+        unnormalized = [G.adj[node][nbr] for nbr in sorted(G.neighbors(node))]
+        norm_const = sum(unnormalized)
+        normalized = [float(u) / norm_const for u in unnormalized]
+        return alias_setup(normalized)
+
+    # src/node2vec.py:133-152
+    def get_alias_edge(self, src, dst):
+        G, p, q = self.G, self.p, self.q
+        unnormalized = []
+        for dst_nbr in sorted(G.neighbors(dst)):
+            if dst_nbr == src:
+                unnormalized.append(G.adj[dst][dst_nbr] / p)
+            elif G.has_edge(dst_nbr, src):
+                unnormalized.append(G.adj[dst][dst_nbr])
+            else:
+                unnormalized.append(G.adj[dst][dst_nbr] / q)
+        norm_const = sum(unnormalized)
+        normalized = [float(u) / norm_const for u in unnormalized]
+        return alias_setup(normalized)
+
+    # src/node2vec.py:176-204
+    def preprocess_transition_probs(self):
+        G = self.G
+        self.alias_nodes = {node: self.get_alias_node(node) for node in G.nodes}
+        alias_edges = {}
+        for (u, v) in G.edges():
+            alias_edges[(u, v)] = self.get_alias_edge(u, v)
+            if not self.is_directed:
+                alias_edges[(v, u)] = self.get_alias_edge(v, u)
+        self.alias_edges = alias_edges
+
+    # src/node2vec.py:55-79 (tables) and :34-53 (on the fly); ``draw`` yields uniforms
+    def node2vec_walk(self, walk_length, start_node, rand, on_the_fly=False):
+        G = self.G
+        walk = [start_node]
+        while len(walk) < walk_length:
+            cur = walk[-1]
+            cur_nbrs = sorted(G.neighbors(cur))
+            if len(cur_nbrs) > 0:
+                if len(walk) == 1:
+                    J, q = self.get_alias_node(cur) if on_the_fly else self.alias_nodes[cur]
+                else:
+                    prev = walk[-2]
+                    J, q = (self.get_alias_edge(prev, cur) if on_the_fly
+                            else self.alias_edges[(prev, cur)])
+                u1 = rand()
+                u2 = rand()
+                walk.append(cur_nbrs[alias_draw_u(J, q, u1, u2)])
+            else:
+                break
+        return walk
+
+    # src/node2vec.py:81-95 / :97-111 — RNG contract of SURVEY.md 8(a) row 6':
+    # the harness seeds numpy's global MT19937, every step takes two random_sample()s.
+    def simulate_walks(self, num_walks, walk_length, nodes=None, seed=None, rand=None,
+                       on_the_fly=False, step_uniforms=None):
+        """``step_uniforms(w, t) -> (u1, u2)`` replaces the sequential stream by a
+        counter-based one (throughput mode: same walk rule, different uniforms)."""
+        if rand is None and step_uniforms is None:
+            rs = np.random.RandomState(seed)
+            rand = rs.random_sample
+        if not nodes:
+            nodes = list(self.G.nodes)
+        walks = []
+        for _ in range(num_walks):
+            for node in nodes:
+                r = rand if step_uniforms is None else _per_walk_rand(step_uniforms, len(walks))
+                walks.append(self.node2vec_walk(walk_length, node, r, on_the_fly))
+        return walks
+
+
+def _per_walk_rand(step_uniforms, w):
+    st = {"t": 0, "u2": None}
+
+    def rand():
+        if st["u2"] is None:
+            u1, st["u2"] = step_uniforms(w, st["t"])
+            return u1
+        u2, st["u2"] = st["u2"], None
+        st["t"] += 1
+        return u2
+    return rand
+
+
+# --------------------------------------------------------------------------- dense (CSR) view
+def to_csr(G):
+    """Dense-index view used by the C oracle and the HIP path.
+
+    Dense id = rank of the label in ascending order, so that ascending dense id ==
+    ascending label == the order alias slots refer to (src/node2vec.py:67,142,185).
+    Returns labels[int64 N], row_ptr[int64 N+1], col[int32 nnz], w[float64 nnz],
+    start_order[int32 N] (dense ids in ``list(G.nodes())`` order).
+    """
+    labels = np.array(sorted(G.nodes), dtype=np.int64)
+    rank = {int(l): i for i, l in enumerate(labels)}
+    row_ptr = np.zeros(len(labels) + 1, dtype=np.int64)
+    col, w = [], []
+    for i, l in enumerate(labels):
+        nb = sorted(G.neighbors(int(l)))
+        col.extend(rank[x] for x in nb)
+        w.extend(float(G.adj[int(l)][x]) for x in nb)
+        row_ptr[i + 1] = len(col)
+    start_order = np.array([rank[v] for v in G.nodes], dtype=np.int32)
+    return labels, row_ptr, np.array(col, dtype=np.int32), np.array(w, dtype=np.float64), start_order
+
+
+# --------------------------------------------------------------------------- Philox4x32-10
+_PH_M0, _PH_M1 = 0xD2511F53, 0xCD9E8D57
+_PH_W0, _PH_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(ctr, key):
+    """Random123 Philox4x32-10 (Salmon et al., SC'11) — the throughput-mode RNG."""
+    c0, c1, c2, c3 = [int(x) & 0xFFFFFFFF for x in ctr]
+    k0, k1 = [int(x) & 0xFFFFFFFF for x in key]
+    for _ in range(10):
+        p0 = _PH_M0 * c0
+        p1 = _PH_M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, \
+                         ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0 = (k0 + _PH_W0) & 0xFFFFFFFF
+        k1 = (k1 + _PH_W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def philox_step_uniforms(seed, walk, step):
+    """Two 53-bit uniforms for (global walk index, 0-based step), built like MT's res53."""
+    r = philox4x32_10((walk & 0xFFFFFFFF, (walk >> 32) & 0xFFFFFFFF, step, 0),
+                      (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    u1 = ((r[0] >> 5) * 67108864.0 + (r[1] >> 6)) / 9007199254740992.0
+    u2 = ((r[2] >> 5) * 67108864.0 + (r[3] >> 6)) / 9007199254740992.0
+    return u1, u2
