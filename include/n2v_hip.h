@@ -1,0 +1,121 @@
+/* n2v_hip.h — C-ABI of the MI355X (gfx950) node2vec walk-and-embed engine.
+ *
+ * The reference (chan0park/node2vec-by-ecc) has no FFI of its own; its seam for this
+ * path is the Python surface of src/node2vec.py and src/main.py.  Each entry point
+ * below names the reference code it replaces (paths relative to the reference root).
+ * The Python binding a maintainer adds is in INTEGRATION.md; the in-tree binding is
+ * node2vec-by-ecc_amd/n2v_hip/_lib.py (ctypes).
+ *
+ * Conventions
+ *  - plain `extern "C"`, no C++/torch types; every pointer is a DEVICE pointer unless the
+ *    parameter name ends in `_host`; the caller allocates and frees everything, the
+ *    library keeps no device memory between calls.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Launches are
+ *    asynchronous on that stream; no call synchronises the device unless stated.
+ *  - return value: N2V_OK (0) or a negative N2V_ERR_*; n2v_last_error() gives the
+ *    message for the calling thread.  Data-dependent failures (zero-sum neighbourhood)
+ *    are reported through a device `status` word the caller reads back.
+ *  - graph layout: dense node ids 0..N-1 assigned by ascending node label, CSR rows
+ *    sorted ascending — so "k-th neighbour in sorted(G.neighbors(v))"
+ *    (src/node2vec.py:67,142,185) is col[row_ptr[v] + k].
+ */
+#ifndef N2V_HIP_H
+#define N2V_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define N2V_ABI_VERSION 1
+
+#define N2V_OK 0
+#define N2V_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, limit exceeded) */
+#define N2V_ERR_HIP (-2)       /* HIP runtime error */
+#define N2V_STATUS_ZERO_NORM 1 /* device status bit: a neighbourhood's weights sum to 0
+                                  (the reference raises ZeroDivisionError, src/node2vec.py:150,187) */
+
+/* One alias slot: (J[k], q[k]) of src/node2vec.py:240-269, 16 B so a draw is one
+ * aligned 16-B load.  `aux` is scratch during construction (Vose's two stacks), then 0. */
+typedef struct n2v_alias_slot {
+    double q;
+    int32_t J;
+    int32_t aux;
+} n2v_alias_slot;
+
+/* One record per CSR entry e = (src -> dst): everything the walk needs to leave `dst`.
+ *   slot  = 40-bit index of dst's transition table for arrivals through e
+ *           (lo 32 bits in slot_lo, hi 8 bits in the top byte of deg_hi)
+ *   base  = row_ptr[dst]           (CSR entry of dst's k-th neighbour is base + k)
+ *   dst   = col[e]
+ *   deg   = low 24 bits of deg_hi  (out-degree of dst; tables have deg slots)
+ * Limits (checked by n2v_build_edge_recs): nnz < 2^32, deg < 2^24, slots < 2^40.        */
+typedef struct n2v_edge_rec {
+    uint32_t slot_lo;
+    uint32_t base;
+    uint32_t dst;
+    uint32_t deg_hi;
+} n2v_edge_rec;
+
+/* ---- queries ------------------------------------------------------------------------ */
+int n2v_abi_version(void);
+const char* n2v_last_error(void);
+
+/* ---- preprocess_transition_probs (src/node2vec.py:176-204) --------------------------- */
+
+/* alias_setup (src/node2vec.py:240-269) for n_tables independent tables: table i occupies
+ * slots[tab_off[i] .. tab_off[i+1]) and on entry slots[].q holds its probabilities (the
+ * `probs` argument); on return q/J are the alias table.  tab_off: int64[n_tables+1].     */
+int n2v_alias_setup_tables(int64_t n_tables, const int64_t* tab_off, n2v_alias_slot* slots, void* stream);
+
+/* Node tables (src/node2vec.py:184-188): slots[row_ptr[v] + k] for every node v.
+ * w == NULL means every weight is 1.  status: int32[1], OR-ed with N2V_STATUS_*.        */
+int n2v_build_node_tables(int64_t n_nodes, const int64_t* row_ptr, const int32_t* col,
+                          const double* w, n2v_alias_slot* slots, int32_t* status, void* stream);
+
+/* Edge tables (src/node2vec.py:133-152,193-199): for CSR entries e in
+ * [e_begin, e_end) — or, if `order` != NULL, for order[i], i in [e_begin, e_end) — the
+ * table of (src -> dst=col[e]) is written to slots[edge_off[e] ...], deg(dst) slots.
+ * edge_off: int64[nnz+1], exclusive prefix sum of deg(col[e]).  `src_of`: int32[nnz], the
+ * row of each CSR entry.  `order` lets the caller bin tables by size (one lane builds one
+ * table, so lanes of a wave should get similar sizes).                                    */
+int n2v_build_edge_tables(int64_t n_nodes, const int64_t* row_ptr, const int32_t* col,
+                          const double* w, const int32_t* src_of, double p, double q,
+                          const int64_t* edge_off, const int32_t* order, int64_t e_begin,
+                          int64_t e_end, n2v_alias_slot* slots, int32_t* status, void* stream);
+
+/* Walk records.  edge_off == NULL: first-order shortcut (p == q == 1), every record
+ * points at dst's node table, slot = slot_base + row_ptr[dst].  Otherwise
+ * slot = slot_base + edge_off[e].  Host-side limit checks need `max_degree` and
+ * `total_slots` (slot_base + last offset).                                              */
+int n2v_build_edge_recs(int64_t n_nodes, int64_t nnz, const int64_t* row_ptr, const int32_t* col,
+                        const int64_t* edge_off, int64_t slot_base, int64_t max_degree,
+                        int64_t total_slots, n2v_edge_rec* recs, void* stream);
+
+/* ---- simulate_walks / node2vec_walk (src/node2vec.py:55-95, :271-281) ---------------- */
+
+#define N2V_RNG_UNIFORMS 0 /* parity mode: two fp64 uniforms per step read from `uniforms` */
+#define N2V_RNG_PHILOX 1   /* throughput mode: Philox4x32-10(seed; global walk index, step) */
+
+/* Walks for start positions [pos_begin, pos_begin+pos_count) of `starts` (dense ids in
+ * list(G.nodes()) order) and rounds [round_begin, round_begin+round_count).
+ * Local walk lw = round_local * pos_count + pos_local; global walk index
+ * gw = (round_begin + round_local) * n_starts + pos_begin + pos_local
+ * (= the reference's position of that walk in the returned list, src/node2vec.py:89-93).
+ * node_slots: table of node v at node_slots[row_ptr[v]...]; recs/slots from the builders
+ * above (slots = the array the recs' 40-bit indices refer to).
+ * N2V_RNG_UNIFORMS: step t (1-based) of local walk lw reads uniforms[o + 2(t-1)], [+1]
+ * with o = walk_uoff ? walk_uoff[lw] : 2*(walk_length-1)*lw.
+ * Output: walks int32[n_local][walk_length] (dense ids, padded with -1), lens int32[n_local]. */
+int n2v_walk(const int64_t* row_ptr, const n2v_alias_slot* node_slots, const n2v_edge_rec* recs,
+             const n2v_alias_slot* slots, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+             int64_t pos_count, int64_t round_begin, int64_t round_count, int32_t walk_length,
+             int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
+             int32_t* walks, int32_t* lens, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* N2V_HIP_H */

@@ -1,0 +1,71 @@
+"""ctypes binding of libn2v_hip.so (the C-ABI declared in include/n2v_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libn2v_hip.so")
+
+N2V_OK = 0
+N2V_STATUS_ZERO_NORM = 1
+RNG_UNIFORMS = 0
+RNG_PHILOX = 1
+
+# name -> (restype, argtypes); mirrors include/n2v_hip.h one to one
+_i64, _i32, _u64, _f64, _ptr = C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_void_p
+SIGNATURES = {
+    "n2v_abi_version": (C.c_int, []),
+    "n2v_last_error": (C.c_char_p, []),
+    "n2v_alias_setup_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr]),
+    "n2v_build_node_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "n2v_build_edge_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _f64, _f64, _ptr, _ptr, _i64, _i64,
+                                        _ptr, _ptr, _ptr]),
+    "n2v_build_edge_recs": (C.c_int, [_i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr]),
+    "n2v_walk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr,
+                           _u64, _ptr, _ptr, _ptr]),
+}
+
+_lib = None
+
+
+class N2VError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "libn2v_hip.so not found at %s — build it with `python __graft_entry__.py` "
+            "(or `make -C node2vec-by-ecc_amd/csrc`); there is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != N2V_OK:
+        msg = load().n2v_last_error()
+        raise N2VError("libn2v_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "non-contiguous tensor passed to the C-ABI"
+    return t.data_ptr()
+
+
+def stream_ptr(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,183 @@
+"""Device-side walk engine: CSR + alias tables resident in HBM as torch tensors, every
+arithmetic step done by the HIP kernels behind the C-ABI (include/n2v_hip.h).
+
+torch is used for memory, streams and index plumbing (prefix sums, size-order sort);
+the alias arithmetic and the walk are never done in torch and there is no CPU path.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .csr import CsrGraph
+
+SLOT_BYTES = 16  # sizeof(n2v_alias_slot)
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("n2v_hip: no GPU visible (torch.cuda.is_available() is False); "
+                           "this engine has no CPU fallback")
+    return torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+
+
+class WalkEngine:
+    """Owns the HBM-resident graph and tables for one (graph, p, q)."""
+
+    def __init__(self, csr: CsrGraph, p, q, device=None):
+        self.lib = _lib.load()
+        self.device = _require_gpu(device)
+        self.csr = csr
+        self.p = float(p)
+        self.q = float(q)
+        d = self.device
+        self.row_ptr = torch.from_numpy(csr.row_ptr).to(d)
+        self.col = torch.from_numpy(csr.col).to(d)
+        self.w = None if csr.w is None else torch.from_numpy(csr.w).to(d)
+        self.start_order = torch.from_numpy(csr.start_order).to(d)
+        self.deg = (self.row_ptr[1:] - self.row_ptr[:-1])
+        self.max_degree = int(self.deg.max().item()) if csr.n_nodes else 0
+        self.node_slots = None
+        self.edge_slots = None
+        self.edge_off = None
+        self.recs = None
+        self.first_order = False
+
+    # ------------------------------------------------------------------ tables
+    def _stream(self):
+        return _lib.stream_ptr(self.device)
+
+    def preprocess(self, first_order_shortcut=True):
+        """preprocess_transition_probs (src/node2vec.py:176-204) on device.
+
+        With p == q == 1 every (src,dst) table is bit-identical to dst's node table
+        (w/1 == w), so the Σdeg² edge tables are not materialised unless
+        ``first_order_shortcut=False``."""
+        csr, d = self.csr, self.device
+        N, nnz = csr.n_nodes, csr.nnz
+        with torch.cuda.device(d):
+            status = torch.zeros(1, dtype=torch.int32, device=d)
+            self.node_slots = torch.zeros((max(nnz, 1), 2), dtype=torch.int64, device=d)
+            _lib.check(self.lib.n2v_build_node_tables(
+                N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(self.node_slots),
+                _lib.ptr(status), self._stream()))
+            self.first_order = bool(first_order_shortcut and self.p == 1.0 and self.q == 1.0)
+            self.recs = torch.empty((max(nnz, 1), 4), dtype=torch.int32, device=d)
+            if self.first_order:
+                self.edge_off = None
+                self.edge_slots = self.node_slots
+                total = nnz
+            else:
+                kdst = self.deg[self.col.long()]
+                self.edge_off = torch.zeros(nnz + 1, dtype=torch.int64, device=d)
+                torch.cumsum(kdst, 0, out=self.edge_off[1:])
+                total = int(self.edge_off[-1].item())
+                free, _ = torch.cuda.mem_get_info(d)
+                need = total * SLOT_BYTES
+                if need > free - (1 << 30):
+                    raise MemoryError(
+                        "edge alias tables need %.1f GB (sum of deg^2 = %d slots), %.1f GB free"
+                        % (need / 1e9, total, free / 1e9))
+                self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
+                order = torch.argsort(kdst, descending=True).to(torch.int32)
+                src_of = torch.repeat_interleave(
+                    torch.arange(N, dtype=torch.int32, device=d), self.deg)
+                _lib.check(self.lib.n2v_build_edge_tables(
+                    N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
+                    self.p, self.q, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz,
+                    _lib.ptr(self.edge_slots), _lib.ptr(status), self._stream()))
+                del order, src_of, kdst
+            _lib.check(self.lib.n2v_build_edge_recs(
+                N, nnz, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.edge_off), 0,
+                self.max_degree, total, _lib.ptr(self.recs), self._stream()))
+            st = int(status.item())
+        if st & _lib.N2V_STATUS_ZERO_NORM:
+            self.node_slots = self.edge_slots = self.recs = None
+            raise ZeroDivisionError("float division by zero")
+        self.total_slots = total
+
+    @property
+    def ready(self):
+        return self.recs is not None
+
+    # raw views used by the dict-like alias_nodes / alias_edges and by the tests
+    @staticmethod
+    def slots_q(slots):
+        return slots.view(torch.float64)[:, 0]
+
+    @staticmethod
+    def slots_J(slots):
+        return slots.view(torch.int32)[:, 2]
+
+    def node_table(self, dense):
+        b, e = int(self.csr.row_ptr[dense]), int(self.csr.row_ptr[dense + 1])
+        s = self.node_slots[b:e]
+        return (self.slots_J(s).cpu().numpy().astype(np.int64), self.slots_q(s).cpu().numpy())
+
+    def edge_index(self, du, dv):
+        """CSR entry of (du -> dv) or -1."""
+        b, e = int(self.csr.row_ptr[du]), int(self.csr.row_ptr[du + 1])
+        k = int(np.searchsorted(self.csr.col[b:e], dv))
+        if k < e - b and self.csr.col[b + k] == dv:
+            return b + k
+        return -1
+
+    def edge_table(self, e):
+        if self.first_order:
+            return self.node_table(int(self.csr.col[e]))
+        off = self.edge_off[e:e + 2].cpu().tolist()
+        s = self.edge_slots[off[0]:off[1]]
+        return (self.slots_J(s).cpu().numpy().astype(np.int64), self.slots_q(s).cpu().numpy())
+
+    # ------------------------------------------------------------------ walks
+    def walk(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
+             pos_begin=0, pos_count=None, round_begin=0, out=None):
+        """Launch the walk kernel.  ``starts``: int32 device tensor of dense ids (the
+        start order).  Returns (walks int32[n_local, L], lens int32[n_local]) on device."""
+        if not self.ready:
+            raise RuntimeError("preprocess() first")
+        d = self.device
+        L = int(walk_length)
+        if L < 1:
+            raise ValueError("walk_length must be >= 1")
+        n_starts = int(starts.numel())
+        if pos_count is None:
+            pos_count = n_starts - pos_begin
+        n_local = pos_count * num_rounds
+        with torch.cuda.device(d):
+            if out is None:
+                walks = torch.empty((n_local, L), dtype=torch.int32, device=d)
+                lens = torch.empty(n_local, dtype=torch.int32, device=d)
+            else:
+                walks, lens = out
+                assert walks.shape == (n_local, L) and walks.dtype == torch.int32 and walks.is_contiguous()
+            mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
+            _lib.check(self.lib.n2v_walk(
+                _lib.ptr(self.row_ptr), _lib.ptr(self.node_slots), _lib.ptr(self.recs),
+                _lib.ptr(self.edge_slots), _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin,
+                num_rounds, L, mode, _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1),
+                _lib.ptr(walks), _lib.ptr(lens), self._stream()))
+        return walks, lens
+
+
+def alias_setup_device(prob_tables, device=None):
+    """alias_setup (src/node2vec.py:240-269) for one table (a flat list of probabilities)
+    or a list of tables; returns (J int64, q float64) per table, computed on the GPU."""
+    single = len(prob_tables) == 0 or not hasattr(prob_tables[0], "__len__")
+    tables = [prob_tables] if single else list(prob_tables)
+    d = _require_gpu(device)
+    lib = _lib.load()
+    sizes = np.array([len(t) for t in tables], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    total = int(off[-1])
+    host = np.zeros((max(total, 1), 2), dtype=np.int64)
+    if total:
+        host.view(np.float64)[:total, 0] = np.concatenate([np.asarray(t, dtype=np.float64) for t in tables if len(t)])
+    with torch.cuda.device(d):
+        slots = torch.from_numpy(host).to(d)
+        off_d = torch.from_numpy(off).to(d)
+        _lib.check(lib.n2v_alias_setup_tables(len(tables), _lib.ptr(off_d), _lib.ptr(slots), _lib.stream_ptr(d)))
+        out = slots.cpu().numpy()
+    q = out.view(np.float64)[:, 0]
+    J = out.view(np.int32)[:, 2]
+    res = [(J[off[i]:off[i + 1]].astype(np.int64), q[off[i]:off[i + 1]].copy()) for i in range(len(tables))]
+    return res[0] if single else res

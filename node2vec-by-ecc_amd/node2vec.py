@@ -1,0 +1,321 @@
+"""Drop-in for the reference's ``src/node2vec.py`` on MI355X.
+
+Same surface — ``Graph(nx_G, is_directed, p, q, popwalk="none")``,
+``.preprocess_transition_probs()``, ``.simulate_walks(num_walks, walk_length, nodes=None,
+verbose=False)``, ``.simulate_walks_on_the_fly(...)``, ``.node2vec_walk(walk_length,
+start_node)``, module-level ``alias_setup`` / ``alias_draw`` — with the tables and the
+walks computed by the HIP kernels in ``csrc/`` through the C-ABI of ``include/n2v_hip.h``.
+
+RNG contract (SURVEY.md 8(a) row 6'): the reference draws two ``np.random.rand()`` per step
+from numpy's GLOBAL MT19937 state.  In the default ``rng="numpy"`` mode this class takes
+exactly the uniforms the reference would take from that same global state (so a harness
+that calls ``np.random.seed(s)`` first gets bit-identical walks, and the global state
+afterwards is where the reference would have left it) and the kernel consumes them by
+(walk, step) index.  ``rng="philox"`` is the throughput mode: uniforms are generated in
+the kernel (Philox4x32-10 keyed by ``seed`` and the walk's global index), nothing is read
+from numpy; the walk rule is identical.
+
+Only ``popwalk="none"`` is implemented (the "pop" variants of the reference are an
+experiment knob outside the hot path).
+"""
+import numpy as np
+import torch
+
+from n2v_hip import csr as _csr
+from n2v_hip.engine import WalkEngine
+
+
+# --------------------------------------------------------------------------- module-level API
+def alias_setup(probs):
+    """src/node2vec.py:240-269 — one table, built on the GPU by the kernel that builds
+    every other table (n2v_alias_setup_tables)."""
+    from n2v_hip.engine import alias_setup_device
+    return alias_setup_device([float(x) for x in probs])
+
+
+def alias_draw(J, q):
+    """src/node2vec.py:271-281 — host helper kept for API compatibility (two draws from
+    numpy's global stream, both always consumed)."""
+    K = len(J)
+    kk = int(np.floor(np.random.rand() * K))
+    if np.random.rand() < q[kk]:
+        return kk
+    return J[kk]
+
+
+class WalkCorpus:
+    """The list of walks ``simulate_walks`` returns, kept on the device.
+
+    Behaves like the reference's ``list[list[int]]`` (len, indexing, iteration, ==),
+    holding node LABELS; ``walks``/``lens`` are the device tensors of DENSE ids that
+    ``learn_embeddings`` consumes without a host round trip."""
+
+    def __init__(self, walks, lens, labels):
+        self.walks = walks    # int32 [W, L] device, padded with -1
+        self.lens = lens      # int32 [W] device
+        self.labels = labels  # int64 [N] host (dense id -> label)
+        self._host = None
+
+    def _materialise(self):
+        if self._host is None:
+            w = self.walks.cpu().numpy()
+            n = self.lens.cpu().numpy()
+            lab = self.labels
+            if (n == w.shape[1]).all():
+                self._host = lab[w].tolist() if w.size else [[] for _ in range(len(n))]
+            else:
+                self._host = [lab[row[:k]].tolist() for row, k in zip(w, n)]
+        return self._host
+
+    def tolist(self):
+        return self._materialise()
+
+    def __len__(self):
+        return int(self.walks.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self._materialise()[i]
+        k = int(self.lens[i].item())
+        return self.labels[self.walks[i, :k].cpu().numpy()].tolist()
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __eq__(self, other):
+        if isinstance(other, WalkCorpus):
+            other = other.tolist()
+        return self._materialise() == other
+
+    def __add__(self, other):
+        return self._materialise() + list(other)
+
+    def __repr__(self):
+        return "WalkCorpus(%d walks x %d)" % tuple(self.walks.shape)
+
+
+class _AliasNodes:
+    """Dict-like view of the node tables: ``alias_nodes[node] -> (J, q)``."""
+
+    def __init__(self, graph):
+        self._g = graph
+
+    def __getitem__(self, node):
+        g = self._g
+        return g._engine.node_table(int(g._csr.dense_of([node])[0]))
+
+    def __contains__(self, node):
+        try:
+            self._g._csr.dense_of([node])
+            return True
+        except (KeyError, TypeError, ValueError):
+            return False
+
+    def __len__(self):
+        return self._g._csr.n_nodes
+
+    def keys(self):
+        return [int(x) for x in self._g._csr.labels[self._g._csr.start_order]]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def items(self):
+        return ((k, self[k]) for k in self.keys())
+
+
+class _AliasEdges:
+    """Dict-like view of the edge tables: ``alias_edges[(src, dst)] -> (J, q)``; keys are the
+    directed adjacency entries (both orientations of an undirected edge), as in
+    src/node2vec.py:193-199."""
+
+    def __init__(self, graph):
+        self._g = graph
+
+    def _entry(self, key):
+        g = self._g
+        try:
+            u, v = key
+            du, dv = g._csr.dense_of([u])[0], g._csr.dense_of([v])[0]
+        except (KeyError, TypeError, ValueError):
+            raise KeyError(key)
+        e = g._engine.edge_index(int(du), int(dv))
+        if e < 0:
+            raise KeyError(key)
+        return e
+
+    def __getitem__(self, key):
+        return self._g._engine.edge_table(self._entry(key))
+
+    def __contains__(self, key):
+        try:
+            self._entry(key)
+            return True
+        except KeyError:
+            return False
+
+    def __len__(self):
+        return self._g._csr.nnz
+
+    def keys(self):
+        c = self._g._csr
+        lab = c.labels
+        return list(zip(lab[c.src_of()].tolist(), lab[c.col].tolist()))
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def items(self):
+        return ((k, self[k]) for k in self.keys())
+
+
+class Graph():
+    def __init__(self, nx_G, is_directed, p, q, popwalk="none", device=None, rng="numpy", seed=0):
+        self.G = nx_G
+        self.is_directed = is_directed
+        self.p = p
+        self.q = q
+        self.popwalk = popwalk
+        self.device = device
+        self.rng = rng
+        self.seed = seed
+        self._csr_cache = None
+        self._engine = None
+
+    # construction without networkx for graphs too large for a dict-of-dict container
+    @classmethod
+    def from_csr(cls, csr_graph, p, q, device=None, rng="philox", seed=0):
+        g = cls(None, csr_graph.directed, p, q, device=device, rng=rng, seed=seed)
+        g._csr_cache = csr_graph
+        return g
+
+    @property
+    def _csr(self):
+        if self._csr_cache is None:
+            if isinstance(self.G, _csr.CsrGraph):
+                self._csr_cache = self.G
+            else:
+                self._csr_cache = _csr.from_networkx(self.G)
+        return self._csr_cache
+
+    def _check_popwalk(self):
+        if self.popwalk != "none":
+            raise NotImplementedError("popwalk=%r: only the 'none' walk is on the MI355X hot path" % (self.popwalk,))
+
+    # src/node2vec.py:176-204
+    def preprocess_transition_probs(self):
+        self._check_popwalk()
+        if self.p == 0 or self.q == 0:
+            raise ZeroDivisionError("float division by zero")
+        eng = WalkEngine(self._csr, self.p, self.q, device=self.device)
+        eng.preprocess()
+        self._engine = eng
+        self.alias_nodes = _AliasNodes(self)
+        self.alias_edges = _AliasEdges(self)
+        return
+
+    def _starts(self, nodes):
+        c = self._csr
+        if not nodes:
+            return c.start_order
+        return c.dense_of(list(nodes))
+
+    # src/node2vec.py:81-95
+    def simulate_walks(self, num_walks, walk_length, nodes=None, verbose=False):
+        '''
+        Repeatedly simulate random walks from each node.
+        '''
+        if self._engine is None:
+            raise AttributeError("'Graph' object has no attribute 'alias_nodes'")  # as the reference would
+        if verbose:
+            for walk_iter in range(num_walks):
+                print(str(walk_iter + 1), '/', str(num_walks))
+        walks, lens = self._simulate(num_walks, walk_length, self._starts(nodes))
+        return WalkCorpus(walks, lens, self._csr.labels)
+
+    # src/node2vec.py:97-111 — identical output to simulate_walks for popwalk == "none";
+    # the tables are built on first use instead of per step.
+    def simulate_walks_on_the_fly(self, num_walks, walk_length, nodes=None, verbose=False):
+        if self._engine is None:
+            self.preprocess_transition_probs()
+        return self.simulate_walks(num_walks, walk_length, nodes=nodes, verbose=verbose)
+
+    # src/node2vec.py:55-79
+    def node2vec_walk(self, walk_length, start_node):
+        if self._engine is None:
+            raise AttributeError("'Graph' object has no attribute 'alias_nodes'")
+        walks, lens = self._simulate(1, walk_length, self._csr.dense_of([start_node]))
+        return WalkCorpus(walks, lens, self._csr.labels)[0]
+
+    def node2vec_walk_on_the_fly(self, walk_length, start_node):
+        if self._engine is None:
+            self.preprocess_transition_probs()
+        return self.node2vec_walk(walk_length, start_node)
+
+    # ------------------------------------------------------------------ internals
+    def _simulate(self, num_walks, walk_length, starts_host):
+        eng = self._engine
+        d = eng.device
+        L = max(int(walk_length), 1)  # walk = [start] even for walk_length <= 1 (:63-65)
+        num_walks = int(num_walks)
+        starts = torch.from_numpy(np.ascontiguousarray(starts_host, dtype=np.int32)).to(d)
+        n = int(starts.numel())
+        if n * num_walks == 0:
+            return (torch.empty((0, L), dtype=torch.int32, device=d), torch.empty(0, dtype=torch.int32, device=d))
+        if self.rng == "philox":
+            return eng.walk(starts, num_walks, L, rng="philox", seed=self.seed)
+        if self.rng != "numpy":
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        return self._simulate_numpy_stream(starts, n, num_walks, L)
+
+    def _simulate_numpy_stream(self, starts, n, num_walks, L):
+        """Parity mode.  Walk w = it*n + pos owns the uniforms the sequential reference
+        loop would have handed it: offset 2 * sum_{w' < w} (len(w') - 1)."""
+        eng = self._engine
+        d = eng.device
+        W = n * num_walks
+        active = (eng.deg[starts.long()] > 0)
+        per_round = active.to(torch.int64) * (2 * (L - 1))
+        uoff = torch.cumsum(per_round.repeat(num_walks), 0)
+        total_full = int(uoff[-1].item())
+        uoff = torch.cat([torch.zeros(1, dtype=torch.int64, device=d), uoff[:-1]]).contiguous()
+        if total_full == 0:
+            return eng.walk(starts, num_walks, L, rng="uniforms",
+                            uniforms=torch.zeros(2, dtype=torch.float64, device=d), walk_uoff=uoff)
+        # a walk can end early only at a node without out-neighbours that is reachable,
+        # i.e. never on an undirected graph (every visited node has the edge it came by)
+        may_end_early = bool(self._csr.directed) and bool((eng.deg == 0).any().item())
+        if not may_end_early:
+            # every round consumes the same number of uniforms: stream them round-wise so
+            # the host never holds more than ~1 GiB of the MT19937 stream at a time
+            per = int(per_round.sum().item())
+            uoff_round = uoff[:n].contiguous()
+            walks = torch.empty((W, L), dtype=torch.int32, device=d)
+            lens = torch.empty(W, dtype=torch.int32, device=d)
+            rounds_per_chunk = max(1, min(num_walks, (1 << 27) // max(per, 1)))
+            it = 0
+            while it < num_walks:
+                k = min(rounds_per_chunk, num_walks - it)
+                U = torch.from_numpy(np.random.random_sample(per * k)).to(d)
+                off = uoff[:n * k].contiguous() if k > 1 else uoff_round
+                eng.walk(starts, k, L, rng="uniforms", uniforms=U, walk_uoff=off, round_begin=it,
+                         out=(walks[it * n:(it + k) * n], lens[it * n:(it + k) * n]))
+                it += k
+            return walks, lens
+        state = np.random.get_state()
+        U = torch.from_numpy(np.random.random_sample(total_full)).to(d)
+        walks, lens = eng.walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
+        # offsets depend on the lengths of all earlier walks: iterate to the fixed point
+        # (each pass makes at least the first not-yet-final walk final)
+        for _ in range(W + 1):
+            new_off = torch.cumsum((lens.to(torch.int64) - 1) * 2, 0)
+            new_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=d), new_off[:-1]]).contiguous()
+            if torch.equal(new_off, uoff):
+                break
+            uoff = new_off
+            walks, lens = eng.walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
+        used = int(((lens.to(torch.int64) - 1) * 2).sum().item())
+        np.random.set_state(state)
+        if used:
+            np.random.random_sample(used)  # leave the global stream where the reference would
+        return walks, lens

@@ -1,0 +1,223 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the
+C-ABI and the drop-in ``node2vec`` module, against (1) the golden vectors captured from the
+reference and (2) the oracle on seeded inputs.  Bar: bit-exact (tables: int J and the raw
+bits of fp64 q; walks: identical node sequences)."""
+import numpy as np
+import pytest
+
+from helpers import GRAPH_CASES, case_weights, golden_walks, load_case, oracle_graph, walks_from_padded
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _nx_graph(z):
+    import networkx as nx
+    G = nx.DiGraph()
+    for (u, v), w in zip(z["edges"].tolist(), case_weights(z)):
+        G.add_edge(int(u), int(v), weight=w)
+    if not bool(z["directed"]):
+        G = G.to_undirected()
+    return G
+
+
+@pytest.fixture(scope="module")
+def n2v():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import node2vec
+    return node2vec
+
+
+def test_alias_setup_known_answers_gpu(n2v, golden_dir):
+    z = dict(np.load(golden_dir + "/alias_setup.npz"))
+    ptr = z["ptr"]
+    from n2v_hip.engine import alias_setup_device
+    tables = [z["probs"][ptr[t]:ptr[t + 1]].tolist() for t in range(len(ptr) - 1)]
+    nonempty = [t for t in tables if len(t)]
+    res = alias_setup_device(nonempty)
+    i = 0
+    for t, pr in enumerate(tables):
+        if not len(pr):
+            J, q = n2v.alias_setup([])
+            assert len(J) == 0 and len(q) == 0
+            continue
+        J, q = res[i]
+        i += 1
+        assert np.array_equal(J, z["J"][ptr[t]:ptr[t + 1]]), t
+        assert np.array_equal(_bits(q), _bits(z["q"][ptr[t]:ptr[t + 1]])), t
+    # single-table module-level entry point (src/node2vec.py:240)
+    J, q = n2v.alias_setup(tables[140])
+    assert np.array_equal(J, z["J"][ptr[140]:ptr[141]]) and J.dtype == np.int64
+    assert np.array_equal(_bits(q), _bits(z["q"][ptr[140]:ptr[141]]))
+
+
+@pytest.mark.parametrize("name", GRAPH_CASES)
+def test_tables_match_reference(n2v, name):
+    z = load_case(name)
+    g = n2v.Graph(_nx_graph(z), bool(z["directed"]), float(z["p"]), float(z["q"]))
+    assert g.preprocess_transition_probs() is None
+    eng = g._engine
+    if eng.first_order:  # p == q == 1 shares tables; also check the materialised form
+        eng.preprocess(first_order_shortcut=False)
+    ap = z["adj_ptr"]
+    nodes = z["nodes"].tolist()
+    assert g.alias_nodes.keys() == nodes
+    nq = eng.slots_q(eng.node_slots).cpu().numpy()
+    nJ = eng.slots_J(eng.node_slots).cpu().numpy()
+    csr = g._csr
+    for i, v in enumerate(nodes):
+        d = int(csr.dense_of([v])[0])
+        sl = slice(int(csr.row_ptr[d]), int(csr.row_ptr[d + 1]))
+        assert np.array_equal(csr.labels[csr.col[sl]], z["adj"][ap[i]:ap[i + 1]])
+        assert np.array_equal(nJ[sl], z["an_J"][ap[i]:ap[i + 1]])
+        assert np.array_equal(_bits(nq[sl]), _bits(z["an_q"][ap[i]:ap[i + 1]]))
+    J0, q0 = g.alias_nodes[nodes[0]]
+    assert J0.dtype == np.int64 and np.array_equal(J0, z["an_J"][ap[0]:ap[1]])
+
+    eq = eng.slots_q(eng.edge_slots).cpu().numpy()
+    eJ = eng.slots_J(eng.edge_slots).cpu().numpy()
+    eoff = eng.edge_off.cpu().numpy()
+    ep = z["ae_ptr"]
+    assert len(g.alias_edges) == len(z["ae_keys"])
+    assert sorted(g.alias_edges.keys()) == sorted(map(tuple, z["ae_keys"].tolist()))
+    for i, (u, v) in enumerate(z["ae_keys"].tolist()):
+        e = eng.edge_index(int(csr.dense_of([u])[0]), int(csr.dense_of([v])[0]))
+        assert e >= 0
+        sl = slice(eoff[e], eoff[e + 1])
+        assert np.array_equal(eJ[sl], z["ae_J"][ep[i]:ep[i + 1]]), (u, v)
+        assert np.array_equal(_bits(eq[sl]), _bits(z["ae_q"][ep[i]:ep[i + 1]])), (u, v)
+    k = tuple(z["ae_keys"][0].tolist())
+    Jk, qk = g.alias_edges[k]
+    assert np.array_equal(Jk, z["ae_J"][ep[0]:ep[1]]) and np.array_equal(_bits(qk), _bits(z["ae_q"][ep[0]:ep[1]]))
+    assert (10**15, 1) not in g.alias_edges
+    with pytest.raises(KeyError):
+        g.alias_edges[(nodes[0], 10**15)]
+
+
+@pytest.mark.parametrize("name", GRAPH_CASES)
+def test_walks_match_reference_under_numpy_seed(n2v, name):
+    """np.random.seed(s); G.simulate_walks(...) == the reference's output, and the global
+    MT19937 stream is left exactly where the reference leaves it."""
+    z = load_case(name)
+    g = n2v.Graph(_nx_graph(z), bool(z["directed"]), float(z["p"]), float(z["q"]))
+    g.preprocess_transition_probs()
+    for i, (seed, r, L, ndraws, has_sub, fly) in enumerate(z["walk_meta"].tolist()):
+        sub = z["walks_%d_subset" % i].tolist() if has_sub else None
+        np.random.seed(seed)
+        fn = g.simulate_walks_on_the_fly if fly else g.simulate_walks
+        walks = fn(r, L, nodes=sub)
+        want = golden_walks(z, i)
+        assert len(walks) == len(want)
+        assert walks == want, (name, i)
+        chk = np.random.RandomState(seed)
+        chk.random_sample(ndraws)
+        assert np.random.random_sample() == chk.random_sample(), (name, i, "global stream position")
+    # node2vec_walk (src/node2vec.py:55-79), used directly by the reference's pool workers
+    np.random.seed(77)
+    start = z["nodes"].tolist()[0]
+    w1 = g.node2vec_walk(12, start)
+    from oracle import n2v_oracle as orc
+    o = orc.Node2VecOracle(oracle_graph(z), bool(z["directed"]), float(z["p"]), float(z["q"]))
+    rs = np.random.RandomState(77)
+    assert w1 == o.node2vec_walk(12, start, rs.random_sample, on_the_fly=True)
+
+
+def test_unknown_start_node_raises(n2v):
+    z = load_case("karate_p1_q1")
+    g = n2v.Graph(_nx_graph(z), False, 1, 1)
+    g.preprocess_transition_probs()
+    with pytest.raises(KeyError):
+        g.simulate_walks(1, 5, nodes=[1, 999])
+
+
+def test_zero_weight_raises_zero_division(n2v):
+    import networkx as nx
+    G = nx.Graph()
+    G.add_edge(0, 1, weight=0.0)
+    G.add_edge(1, 2, weight=0.0)
+    g = n2v.Graph(G, False, 1, 1)
+    with pytest.raises(ZeroDivisionError):
+        g.preprocess_transition_probs()
+    g = n2v.Graph(G, False, 0.5, 2)
+    with pytest.raises(ZeroDivisionError):
+        g.preprocess_transition_probs()
+
+
+def _random_graph(n, m, seed, weighted, directed):
+    rs = np.random.RandomState(seed)
+    src = rs.randint(0, n, size=m)
+    dst = rs.randint(0, n, size=m)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    w = (rs.random_sample(len(src)) * 3 + 0.25) if weighted else None
+    from n2v_hip import csr
+    return csr.from_edges(src, dst, w, directed)
+
+
+@pytest.mark.parametrize("weighted,directed,p,q", [(False, False, 0.25, 4.0), (True, False, 2.0, 0.5),
+                                                     (True, True, 0.5, 2.0), (False, False, 1.0, 1.0)])
+def test_tables_and_walks_vs_c_oracle_20k(n2v, weighted, directed, p, q):
+    """20k nodes / ~100k edges: every slot of every table and every walk vs the C oracle,
+    in parity mode (uniform buffer) and in throughput mode (Philox)."""
+    import torch
+    from oracle import c_oracle
+    cg = _random_graph(20000, 100000, 5, weighted, directed)
+    g = n2v.Graph.from_csr(cg, p, q, rng="philox", seed=0xC0FFEE1234)
+    g.preprocess_transition_probs()
+    eng = g._engine
+    co = c_oracle.CsrOracle(cg.row_ptr, cg.col, cg.w, p, q)
+    co.preprocess(first_order_shortcut=eng.first_order)
+    assert np.array_equal(eng.slots_J(eng.node_slots).cpu().numpy()[:cg.nnz], co.nodeJ)
+    assert np.array_equal(_bits(eng.slots_q(eng.node_slots).cpu().numpy()[:cg.nnz]), _bits(co.nodeq))
+    if not eng.first_order:
+        assert np.array_equal(eng.edge_off.cpu().numpy(), co.edge_off)
+        T = int(co.edge_off[-1])
+        assert np.array_equal(eng.slots_J(eng.edge_slots).cpu().numpy()[:T], co.edgeJ)
+        assert np.array_equal(_bits(eng.slots_q(eng.edge_slots).cpu().numpy()[:T]), _bits(co.edgeq))
+    L, r = 40, 2
+    # throughput mode
+    walks = g.simulate_walks(r, L)
+    ow, ol, _ = co.walk(cg.start_order, r, L, mode="philox", seed=0xC0FFEE1234)
+    assert np.array_equal(walks.lens.cpu().numpy(), ol)
+    assert np.array_equal(walks.walks.cpu().numpy(), ow)
+    # parity mode, sequential stream (directed: ragged walks, offsets found by fixed point)
+    g.rng = "numpy"
+    sub = cg.labels[cg.start_order[:3000]].tolist() if directed else None
+    np.random.seed(42)
+    walks = g.simulate_walks(1, L, nodes=sub)
+    starts = cg.start_order[:3000] if directed else cg.start_order
+    ow, ol, nd = co.walk(starts, 1, L, mode="mt", seed=42)
+    assert np.array_equal(walks.lens.cpu().numpy(), ol)
+    assert np.array_equal(walks.walks.cpu().numpy(), ow)
+    chk = np.random.RandomState(42)
+    chk.random_sample(nd)
+    assert np.random.random_sample() == chk.random_sample()
+    # sharding by start position and by round reproduces the same rows
+    g.rng = "philox"
+    full_w, full_l = eng.walk(eng.start_order, 2, L, rng="philox", seed=9)
+    n = cg.n_nodes
+    a, b = n // 3, n - n // 3
+    for rb in (0, 1):
+        for (pb, pc) in ((0, a), (a, b)):
+            sw, sl = eng.walk(eng.start_order, 1, L, rng="philox", seed=9, pos_begin=pb, pos_count=pc,
+                              round_begin=rb)
+            assert torch.equal(sw, full_w[rb * n + pb: rb * n + pb + pc])
+            assert torch.equal(sl, full_l[rb * n + pb: rb * n + pb + pc])
+
+
+def test_walk_lengths_not_multiple_of_4_and_length_1(n2v):
+    z = load_case("karate_p025_q4")
+    g = n2v.Graph(_nx_graph(z), False, 0.25, 4.0)
+    g.preprocess_transition_probs()
+    from oracle import n2v_oracle as orc
+    o = orc.Node2VecOracle(oracle_graph(z), False, 0.25, 4.0)
+    o.preprocess_transition_probs()
+    for L in (0, 1, 2, 3, 5, 7, 8, 9, 81):
+        np.random.seed(3)
+        got = g.simulate_walks(2, L)
+        want = o.simulate_walks(2, L, seed=3)
+        assert got == want, L
