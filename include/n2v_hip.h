@@ -115,6 +115,43 @@ int n2v_walk(const int64_t* row_ptr, const n2v_alias_slot* node_slots, const n2v
              int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
              int32_t* walks, int32_t* lens, void* stream);
 
+/* ---- learn_embeddings (src/main.py:82-90 -> gensim 3.2.0 Word2Vec, sg=1, negative sampling) --
+ * gensim is a third-party dependency absent from the reference tree (requirements.txt:17);
+ * these entry points restate its public algorithm.
+ * Embedding tables are fp32 [n_words][row_stride] row-major with row_stride a multiple of
+ * 64 floats (64, 128, 256 or 512) >= dim; the padding columns stay 0.  Word index = dense
+ * node id.                                                                               */
+
+/* reset_weights: syn0 ~ U(-0.5/dim, 0.5/dim) (Philox, keyed by seed and row), syn1neg = 0. */
+int n2v_sgns_init(float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                  uint64_t seed, void* stream);
+
+/* Bucket index over gensim's cumulative unigram^0.75 table (cum_table: uint32[n_words],
+ * non-decreasing, last entry 2^31-1): lut[b] = bisect_left(cum_table, b << (31 - lut_bits)),
+ * b in [0, 2^lut_bits]; lut: uint32[2^lut_bits + 1].  A negative draw then costs one
+ * bucket read plus a search over that bucket's few entries and returns exactly
+ * bisect_left(cum_table, r).                                                             */
+int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bits, uint32_t* lut,
+                      void* stream);
+
+/* One pass over `n_walks` sentences (walks: int32[n_walks][walk_stride], -1 padded; lens may
+ * be NULL = all full length).  sample_int: uint32[n_words] keep-thresholds of gensim's
+ * sub-sampling (NULL = off).  Learning rate of sentence s (0-based within this call):
+ *   alpha - (alpha - min_alpha) * (sentences_base + floor(s / alpha_batch) * alpha_batch
+ *           * sentences_step) / sentences_total, floored at min_alpha
+ * (gensim steps alpha once per job of <= 10000 words; sentences_step = number of replicas
+ * advancing together, 1 on a single GPU).  seed/walk_id_base key the
+ * per-sentence random streams (sub-sampling, window shrink, negative draws).
+ * pair_count (may be NULL): incremented by the number of (centre, context) pairs trained.
+ * max_blocks <= 0 picks the default grid (2048 workgroups of 4 wavefronts).              */
+int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
+                   float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                   int32_t window, int32_t negative, const uint32_t* sample_int,
+                   const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
+                   float min_alpha, int64_t sentences_base, int64_t sentences_step,
+                   int64_t sentences_total, int64_t alpha_batch, uint64_t seed, uint64_t walk_id_base,
+                   unsigned long long* pair_count, int32_t max_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,427 @@
+// Skip-gram with negative sampling over a device-resident walk corpus — gfx950 kernels.
+//
+// Replaces what `learn_embeddings` hands to gensim 3.2.0 (src/main.py:82-90:
+// Word2Vec(walks, size=d, window=w, min_count=0, sg=1, iter=...), defaults negative=5,
+// alpha .025 -> .0001, sample=1e-3).  gensim's source is not part of the reference tree;
+// the update rule below restates its public `fast_sentence_sg_neg` / `train_batch_sg`
+// (word2vec_inner.pyx) as summarised in SURVEY.md 8(a) row 9:
+//
+//   per sentence: drop sub-sampled words; per position i draw b in [0, window); for every
+//   j in [i-window+b, i+window-b], j != i:   input row h = syn0[word_j]; targets = word_i
+//   (label 1) + `negative` draws from the unigram^0.75 cum-table (a draw equal to word_i is
+//   skipped); f = <h, syn1neg[t]>; |f| >= 6 skips; g = (label - sigmoid_table[f]) * alpha;
+//   work += g * syn1neg[t]; syn1neg[t] += g * h; finally syn0[word_j] += work.
+//
+// Mapping to the machine: one wavefront owns one walk at a time; a row of d = 64*VPL floats
+// is VPL consecutive floats per lane, so a row access is one coalesced wave-wide load or
+// store (512 B at d = 128).  The centre word's syn1neg row stays in registers for all of
+// its context pairs.  The up-to-8 dot products of a pair are reduced together
+// (DPP / ds_swizzle butterflies that halve the value count at each of the first three
+// steps), so that lane bitrev3(k) ends up with <h, row_k>, evaluates the sigmoid table and
+// the gradient for its own target, and the g's return to all lanes by v_readlane.
+// Rows are updated with plain loads/stores, racing with other wavefronts exactly as
+// gensim's Hogwild worker threads race with each other.  The path is HBM/L2 gather-scatter
+// bound; there is no dense contraction worth an MFMA.
+#include <cmath>
+
+#include "n2v_common.h"
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+constexpr int kExpTableSize = 1000;  // gensim EXP_TABLE_SIZE
+constexpr float kMaxExp = 6.0f;      // gensim MAX_EXP
+__constant__ float c_exp_table[kExpTableSize];
+
+constexpr uint64_t kLcgA = 25214903917ULL, kLcgC = 11ULL, kLcgMask = (1ULL << 48) - 1;
+
+struct SgnsArgs {
+    const int32_t* walks;
+    const int32_t* lens;
+    int64_t n_walks;
+    int32_t walk_stride;
+    float* syn0;
+    float* syn1neg;
+    int32_t row_stride;
+    int32_t window, negative;
+    const uint32_t* sample_int;
+    const uint32_t* cum_table;
+    const uint32_t* lut;
+    int32_t lut_shift;  // 31 - lut_bits
+    float alpha0, min_alpha;
+    int64_t sent_base, sent_step, sent_total, alpha_batch;
+    uint64_t seed, walk_id_base;
+    unsigned long long* pair_count;
+    int32_t lpad;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t walk, uint32_t pos, uint32_t salt) {
+    return (uint32_t)(mix64(seed ^ mix64(walk * 0x9E3779B97F4A7C15ULL + (((uint64_t)salt << 32) | pos))) >> 32);
+}
+
+__device__ __forceinline__ float xor_dpp1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float xor_dpp2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+}
+template <int M>
+__device__ __forceinline__ float xor_swz(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (M << 10) | 0x1f));
+}
+
+// Reduce 8 per-lane partial sums over the wave at once.  On return lane l holds the total
+// of value index 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1), i.e. value k sits in lane bitrev3(k)
+// (and in every lane congruent to it mod 8).
+__device__ __forceinline__ float reduce8(const float (&p)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float q[4], r[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float send = b0 ? p[k] : p[k + 4];
+        const float keep = b0 ? p[k + 4] : p[k];
+        q[k] = keep + xor_dpp1(send);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float send = b1 ? q[k] : q[k + 2];
+        const float keep = b1 ? q[k + 2] : q[k];
+        r[k] = keep + xor_dpp2(send);
+    }
+    float s = (b2 ? r[1] : r[0]) + xor_swz<4>(b2 ? r[0] : r[1]);
+    s += xor_swz<8>(s);
+    s += xor_swz<16>(s);
+    s += __shfl_xor(s, 32);
+    return s;
+}
+
+__device__ __forceinline__ constexpr int bitrev3(int k) { return ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1); }
+
+// bisect_left(cum_table, r) narrowed by a bucket table: lut[b] = bisect_left(cum_table, b << shift)
+__device__ __forceinline__ int32_t draw_target(const uint32_t* __restrict__ cum, const uint32_t* __restrict__ lut,
+                                               int shift, uint32_t r) {
+    const uint32_t b = r >> shift;
+    uint32_t lo = lut[b], hi = lut[b + 1];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cum[mid] < r) lo = mid + 1;
+        else hi = mid;
+    }
+    return (int32_t)lo;
+}
+
+template <int VPL>
+struct Row {
+    float v[VPL];
+};
+
+template <int VPL>
+__device__ __forceinline__ Row<VPL> load_row(const float* base, int64_t row, int stride, int lane) {
+    Row<VPL> r;
+    // VPL <= 2: lane owns VPL consecutive floats; VPL >= 4: 1-KiB chunks, 4 floats per lane each
+    const float* p = base + row * stride + (VPL <= 2 ? lane * VPL : lane * 4);
+    if constexpr (VPL == 1) {
+        r.v[0] = *p;
+    } else if constexpr (VPL == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; i += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p + i * 64);
+            r.v[i] = t.x; r.v[i + 1] = t.y; r.v[i + 2] = t.z; r.v[i + 3] = t.w;
+        }
+    }
+    return r;
+}
+
+template <int VPL>
+__device__ __forceinline__ void store_row(float* base, int64_t row, int stride, int lane, const Row<VPL>& r) {
+    float* p = base + row * stride + (VPL <= 2 ? lane * VPL : lane * 4);
+    if constexpr (VPL == 1) {
+        *p = r.v[0];
+    } else if constexpr (VPL == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; i += 4)
+            *reinterpret_cast<float4*>(p + i * 64) = make_float4(r.v[i], r.v[i + 1], r.v[i + 2], r.v[i + 3]);
+    }
+}
+
+// G = target slots in use per group of 8 (6 when negative == 5: the centre + 5 draws)
+template <int VPL, int G>
+__global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
+    extern __shared__ int32_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t* sent = smem + wv * a.lpad;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int my_k = bitrev3(lane & 7);  // which of the 8 reduced values this lane ends up holding
+    unsigned long long pairs_done = 0;
+
+    for (int64_t wi = (int64_t)blockIdx.x * 4 + wv; wi < a.n_walks; wi += n_waves) {
+        const int len = a.lens ? a.lens[wi] : a.walk_stride;
+        const uint64_t wid = a.walk_id_base + (uint64_t)wi;
+        // ---- effective sentence: drop padding and sub-sampled words, keep order
+        int n_eff = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int pos = base + lane;
+            bool keep = false;
+            int32_t tok = -1;
+            if (pos < len) {
+                tok = a.walks[wi * a.walk_stride + pos];
+                keep = tok >= 0;
+                if (keep && a.sample_int) keep = !(a.sample_int[tok] < hash32(a.seed, wid, (uint32_t)pos, 0x5AB));
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) sent[n_eff + __popcll(m & ((1ULL << lane) - 1ULL))] = tok;
+            n_eff += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- learning rate of this walk (gensim: linear decay, stepped per job)
+        const int64_t pushed = a.sent_base + (wi / a.alpha_batch) * a.alpha_batch * a.sent_step;
+        float alpha = a.alpha0 - (a.alpha0 - a.min_alpha) * (float)((double)pushed / (double)a.sent_total);
+        alpha = fmaxf(alpha, a.min_alpha);
+
+        uint64_t lcg = mix64(a.seed ^ mix64(wid + 0x632BE59BD9B4E019ULL)) & kLcgMask;
+
+        for (int i = 0; i < n_eff; ++i) {
+            const int32_t ci = __builtin_amdgcn_readfirstlane(sent[i]);
+            const int rb = (int)(hash32(a.seed, wid, (uint32_t)i, 0xB17) % (uint32_t)a.window);
+            const int lo = max(0, i - a.window + rb), hi = min(n_eff, i + a.window + 1 - rb);
+            if (hi - lo <= 1) continue;
+            Row<VPL> c = load_row<VPL>(a.syn1neg, ci, a.row_stride, lane);
+            for (int j = lo; j < hi; ++j) {
+                if (j == i) continue;
+                const int32_t xj = __builtin_amdgcn_readfirstlane(sent[j]);
+                Row<VPL> h = load_row<VPL>(a.syn0, xj, a.row_stride, lane);
+                Row<VPL> work;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) work.v[v] = 0.f;
+                // targets are processed 8 at a time: slot 0 of the first group is the centre word
+                for (int t0 = 0; t0 < a.negative + 1; t0 += 8) {
+                    // lane k (k < 8) draws the target of slot k of this group
+                    int32_t my_t = -1;
+                    {
+                        const int tk = t0 + lane;  // target number: 0 = positive, d >= 1 = d-th negative
+                        if (lane < 8 && tk >= 1 && tk <= a.negative) {
+                            uint64_t s = lcg;  // state of the first draw of this group
+                            for (int d = max(t0, 1); d < tk; ++d) s = (s * kLcgA + kLcgC) & kLcgMask;
+                            const uint32_t r = (uint32_t)((s >> 16) % 2147483647ULL);
+                            my_t = draw_target(a.cum_table, a.lut, a.lut_shift, r);
+                            if (my_t == ci) my_t = -1;  // `if target_index == word_index: continue`
+                        }
+                    }
+                    int32_t tgt[G];
+                    Row<VPL> n[G];
+                    float p[8];
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        tgt[k] = __builtin_amdgcn_readlane(my_t, k);
+                        if (k == 0 && t0 == 0) tgt[k] = ci;
+                    }
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        if (k == 0 && t0 == 0) {
+                            n[k] = c;
+                        } else if (tgt[k] >= 0) {
+                            n[k] = load_row<VPL>(a.syn1neg, tgt[k], a.row_stride, lane);
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < VPL; ++v) n[k].v[v] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float acc = 0.f;
+                        if (k < G) {
+#pragma unroll
+                            for (int v = 0; v < VPL; ++v) acc = fmaf(h.v[v], n[k].v[v], acc);
+                        }
+                        p[k] = acc;
+                    }
+                    const float f = reduce8(p, lane);
+                    // this lane's own target: sigmoid table, gradient
+                    float g = 0.f;
+                    if (f > -kMaxExp && f < kMaxExp) {
+                        const float sig = c_exp_table[(int)((f + kMaxExp) * (float)(kExpTableSize / (int)kMaxExp / 2))];
+                        const float label = (my_k == 0 && t0 == 0) ? 1.f : 0.f;
+                        g = (label - sig) * alpha;
+                    }
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        if (tgt[k] < 0) continue;
+                        const float gk = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), bitrev3(k)));
+                        if (gk == 0.f) continue;  // |f| >= MAX_EXP: no update at all
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v) {
+                            work.v[v] = fmaf(gk, n[k].v[v], work.v[v]);
+                            n[k].v[v] = fmaf(gk, h.v[v], n[k].v[v]);
+                        }
+                        if (k == 0 && t0 == 0) c = n[k];
+                        else store_row<VPL>(a.syn1neg, tgt[k], a.row_stride, lane, n[k]);
+                    }
+                    // advance the walk's LCG past this group's negatives
+                    const int used = min(a.negative, t0 + 7) - max(t0, 1) + 1;
+                    for (int d = 0; d < used; ++d) lcg = (lcg * kLcgA + kLcgC) & kLcgMask;
+                }
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) h.v[v] += work.v[v];
+                store_row<VPL>(a.syn0, xj, a.row_stride, lane, h);
+                ++pairs_done;
+            }
+            store_row<VPL>(a.syn1neg, ci, a.row_stride, lane, c);
+        }
+        __builtin_amdgcn_wave_barrier();  // LDS sentence is reused by the next walk
+    }
+    if (a.pair_count && lane == 0 && pairs_done) atomicAdd(a.pair_count, pairs_done);
+}
+
+// syn0 ~ U(-0.5/d, 0.5/d), syn1neg = 0 (gensim reset_weights); one Philox call per 4 floats,
+// keyed by the seed and counted by (row, column block) so a row does not depend on n_words.
+__global__ void __launch_bounds__(256)
+sgns_init_kernel(float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t stride, uint64_t seed) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per 4 columns
+    const int blocks_per_row = stride / 4;
+    const int64_t row = idx / blocks_per_row;
+    const int cb = (int)(idx - row * blocks_per_row);
+    if (row >= n_words) return;
+    uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32), c2 = (uint32_t)cb, c3 = 0x5EEDu;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t rr[4] = {c0, c1, c2, c3};
+    float4 o, z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* po = &o.x;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int colx = cb * 4 + t;
+        const float u = (float)(rr[t] >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+        po[t] = colx < dim ? (u - 0.5f) / (float)dim : 0.f;
+    }
+    *reinterpret_cast<float4*>(syn0 + row * stride + cb * 4) = o;
+    *reinterpret_cast<float4*>(syn1neg + row * stride + cb * 4) = z;
+}
+
+__global__ void __launch_bounds__(256)
+neg_lut_kernel(const uint32_t* __restrict__ cum, int64_t n_words, int shift, int64_t n_buckets, uint32_t* __restrict__ lut) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b > n_buckets) return;
+    const uint64_t key = (uint64_t)b << shift;
+    int64_t lo = 0, hi = n_words;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)cum[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    lut[b] = (uint32_t)lo;
+}
+
+float host_exp_table[kExpTableSize];
+bool host_exp_ready = false;
+
+void fill_exp_table() {
+    if (host_exp_ready) return;
+    for (int i = 0; i < kExpTableSize; ++i) {
+        // gensim word2vec_inner.pyx init(): EXP_TABLE[i] = exp((i / 1000 * 2 - 1) * 6); e / (e + 1), float32
+        const float x = ((float)i / (float)kExpTableSize * 2.0f - 1.0f) * kMaxExp;
+        const float e = (float)std::exp((double)x);
+        host_exp_table[i] = (float)(e / (e + 1.0f));
+    }
+    host_exp_ready = true;
+}
+
+}  // namespace
+
+extern "C" int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bits, uint32_t* lut,
+                                 void* stream) {
+    if (!cum_table || !lut || n_words <= 0 || n_words >= ((int64_t)1 << 32) || lut_bits < 1 || lut_bits > 24)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_build_neg_lut: bad argument (n_words %lld, lut_bits %d)",
+                         (long long)n_words, (int)lut_bits);
+    const int64_t nb = (int64_t)1 << lut_bits;
+    hipLaunchKernelGGL(neg_lut_kernel, dim3(n2v::grid_for(nb + 1, 256)), dim3(256), 0, (hipStream_t)stream, cum_table,
+                       n_words, 31 - lut_bits, nb, lut);
+    return n2v::check_launch("n2v_build_neg_lut");
+}
+
+extern "C" int n2v_sgns_init(float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                             uint64_t seed, void* stream) {
+    if (!syn0 || !syn1neg || n_words < 0 || dim < 1 || row_stride < dim || (row_stride % 4) != 0)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_init: bad argument");
+    if (n_words == 0) return N2V_OK;
+    const int64_t threads = n_words * (row_stride / 4);
+    hipLaunchKernelGGL(sgns_init_kernel, dim3(n2v::grid_for(threads, 256)), dim3(256), 0, (hipStream_t)stream, syn0,
+                       syn1neg, n_words, dim, row_stride, seed);
+    return n2v::check_launch("n2v_sgns_init");
+}
+
+extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
+                              float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                              int32_t window, int32_t negative, const uint32_t* sample_int,
+                              const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
+                              float min_alpha, int64_t sentences_base, int64_t sentences_step,
+                              int64_t sentences_total, int64_t alpha_batch,
+                              uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
+                              int32_t max_blocks, void* stream) {
+    if (n_walks < 0 || walk_stride < 1 || n_words < 1 || dim < 1 || window < 1 || negative < 0 || negative > 64)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad size (walks %lld x %d, words %lld, dim %d, window %d, negative %d)",
+                         (long long)n_walks, (int)walk_stride, (long long)n_words, (int)dim, (int)window, (int)negative);
+    if (n_walks == 0) return N2V_OK;
+    if (!walks || !syn0 || !syn1neg || (negative > 0 && (!cum_table || !lut)))
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: null pointer");
+    if (row_stride < dim || (row_stride % 64) != 0 || row_stride > 512)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: row_stride %d must be a multiple of 64 in [dim, 512]",
+                         (int)row_stride);
+    if (lut_bits < 1 || lut_bits > 24) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: lut_bits %d", (int)lut_bits);
+    if (sentences_total < 1 || alpha_batch < 1 || sentences_step < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad schedule");
+    hipStream_t st = (hipStream_t)stream;
+    fill_exp_table();
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_exp_table), host_exp_table, sizeof(host_exp_table), 0,
+                                          hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return n2v::fail(N2V_ERR_HIP, "n2v_sgns_train: exp table upload: %s", hipGetErrorString(e));
+
+    SgnsArgs a;
+    a.walks = walks; a.lens = lens; a.n_walks = n_walks; a.walk_stride = walk_stride;
+    a.syn0 = syn0; a.syn1neg = syn1neg; a.row_stride = row_stride;
+    a.window = window; a.negative = negative; a.sample_int = sample_int;
+    a.cum_table = cum_table; a.lut = lut; a.lut_shift = 31 - lut_bits;
+    a.alpha0 = alpha; a.min_alpha = min_alpha;
+    a.sent_base = sentences_base; a.sent_step = sentences_step; a.sent_total = sentences_total;
+    a.alpha_batch = alpha_batch;
+    a.seed = seed; a.walk_id_base = walk_id_base; a.pair_count = pair_count;
+    a.lpad = (walk_stride + 63) & ~63;
+    const size_t shmem = (size_t)4 * a.lpad * sizeof(int32_t);
+    if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
+    int64_t blocks = (n_walks + 3) / 4;
+    const int64_t cap = max_blocks > 0 ? max_blocks : 2048;  // 256 CUs x 8 blocks of 4 waves
+    if (blocks > cap) blocks = cap;
+    const dim3 grid((unsigned)blocks), block(256);
+#define N2V_SGNS_LAUNCH(V)                                                              \
+    if (negative <= 5) hipLaunchKernelGGL((sgns_kernel<V, 6>), grid, block, shmem, st, a); \
+    else hipLaunchKernelGGL((sgns_kernel<V, 8>), grid, block, shmem, st, a)
+    switch (row_stride / 64) {
+        case 1: N2V_SGNS_LAUNCH(1); break;
+        case 2: N2V_SGNS_LAUNCH(2); break;
+        case 4: N2V_SGNS_LAUNCH(4); break;
+        case 8: N2V_SGNS_LAUNCH(8); break;
+        default:
+            return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: row_stride %d must be 64, 128, 256 or 512", (int)row_stride);
+    }
+    return n2v::check_launch("n2v_sgns_train");
+}

@@ -1,0 +1,102 @@
+'''
+Drop-in for the reference's ``src/main.py`` (node2vec pipeline) on MI355X.
+
+Same flags and the same three calls — ``read_graph()``, ``node2vec.Graph(...)``
+-> ``preprocess_transition_probs()`` -> ``simulate_walks()``, ``learn_embeddings(walks)`` —
+with the walk and the skip-gram training done by the HIP kernels of this package instead of
+pure Python + gensim (src/main.py:66-101).  ``learn_embeddings`` reads the module-global
+``args`` exactly as the reference does (src/main.py:87).
+'''
+import argparse
+
+import numpy as np
+
+import node2vec
+from n2v_hip import csr as _csr
+from n2v_hip import sgns as _sgns
+
+args = None
+
+
+def parse_args(argv=None):
+    '''
+    Parses the node2vec arguments (names and defaults of src/main.py:18-64).
+    '''
+    parser = argparse.ArgumentParser(description="Run node2vec.")
+    parser.add_argument('--input', nargs='?', default='graph/karate.edgelist', help='Input graph path')
+    parser.add_argument('--output', nargs='?', default='emb/karate.emb', help='Embeddings path')
+    parser.add_argument('--dimensions', type=int, default=128, help='Number of dimensions. Default is 128.')
+    parser.add_argument('--walk-length', type=int, default=80, help='Length of walk per source. Default is 80.')
+    parser.add_argument('--num-walks', type=int, default=10, help='Number of walks per source. Default is 10.')
+    parser.add_argument('--window-size', type=int, default=10, help='Context size for optimization. Default is 10.')
+    parser.add_argument('--iter', default=1, type=int, help='Number of epochs in SGD')
+    parser.add_argument('--workers', type=int, default=8, help='Accepted for compatibility (the GPU replaces the worker threads).')
+    parser.add_argument('--p', type=float, default=1, help='Return hyperparameter. Default is 1.')
+    parser.add_argument('--q', type=float, default=1, help='Inout hyperparameter. Default is 1.')
+    parser.add_argument('--weighted', dest='weighted', action='store_true',
+                        help='Boolean specifying (un)weighted. Default is unweighted.')
+    parser.add_argument('--unweighted', dest='unweighted', action='store_false')
+    parser.set_defaults(weighted=False)
+    parser.add_argument('--directed', dest='directed', action='store_true',
+                        help='Graph is (un)directed. Default is undirected.')
+    parser.add_argument('--undirected', dest='undirected', action='store_false')
+    parser.set_defaults(directed=False)
+    # extensions (not in the reference): RNG mode of the walk and its seed
+    parser.add_argument('--rng', default='numpy', choices=['numpy', 'philox'],
+                        help="'numpy': consume numpy's global MT19937 stream like the reference; 'philox': in-kernel RNG")
+    parser.add_argument('--seed', type=int, default=1, help='Seed of the philox walk RNG and of the SGNS trainer')
+    return parser.parse_args(argv)
+
+
+def read_graph():
+    '''
+    Reads the input network (src/main.py:66-80) straight into the sorted-CSR container; node
+    order, duplicate lines and the to_undirected() weight rule follow networkx.
+    '''
+    return _csr.read_edgelist(args.input, weighted=args.weighted, directed=args.directed)
+
+
+def learn_embeddings(walks, **overrides):
+    '''
+    Learn embeddings by optimizing the Skipgram objective using SGD (src/main.py:82-90):
+    Word2Vec(walks, size=args.dimensions, window=args.window_size, min_count=0, sg=1,
+    workers=args.workers, iter=args.iter) with gensim's defaults for everything else.
+    `walks` is what simulate_walks returned (a WalkCorpus: stays on the device) or any list
+    of lists of node ids.
+    '''
+    a = args
+    dim = overrides.get("dimensions", getattr(a, "dimensions", 128))
+    window = overrides.get("window_size", getattr(a, "window_size", 10))
+    epochs = overrides.get("iter", getattr(a, "iter", 1))
+    seed = overrides.get("seed", getattr(a, "seed", 1))
+    corpus = node2vec.as_corpus(walks)
+    model = _sgns.SgnsModel(len(corpus.labels), dim=dim, window=window, negative=overrides.get("negative", 5),
+                            alpha=overrides.get("alpha", 0.025), min_alpha=overrides.get("min_alpha", 1e-4),
+                            sample=overrides.get("sample", 1e-3), seed=seed, device=corpus.walks.device)
+    model.build_vocab(corpus.walks)
+    _sgns.train(model, corpus.walks, corpus.lens, epochs=epochs)
+    wv = _sgns.KeyedVectors(corpus.labels, model.counts, model.vectors().cpu().numpy())
+    return _sgns.Word2VecResult(wv, model, model.pairs_trained())
+
+
+def main(args_):
+    '''
+    Pipeline for representational learning for all nodes in a graph (src/main.py:92-101).
+    '''
+    global args
+    args = args_
+    nx_G = read_graph()
+    G = node2vec.Graph(nx_G, args.directed, args.p, args.q, rng=getattr(args, "rng", "numpy"),
+                       seed=getattr(args, "seed", 1))
+    G.preprocess_transition_probs()
+    walks = G.simulate_walks(args.num_walks, args.walk_length)
+    emb = learn_embeddings(walks)
+    return emb
+
+
+if __name__ == "__main__":
+    args = parse_args()
+    emb = main(args)
+    import os
+    if args.output and os.path.isdir(os.path.dirname(args.output) or "."):
+        emb.wv.save_word2vec_format(args.output)

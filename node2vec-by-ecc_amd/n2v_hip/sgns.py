@@ -1,0 +1,274 @@
+"""Host side of the skip-gram / negative-sampling trainer (the gensim ``Word2Vec`` call of
+src/main.py:82-90) on MI355X: vocabulary statistics and the schedule are prepared here,
+every row update runs in the HIP kernel ``n2v_sgns_train`` (csrc/n2v_sgns.hip).
+
+gensim 3.2.0 (requirements.txt:17) is a third-party dependency that is not part of the
+reference tree; the statistics below restate its public ``scale_vocab`` / ``make_cum_table``
+/ job-wise learning-rate decay with the arguments the reference passes
+(size=d, window, min_count=0, sg=1, iter) and gensim's defaults for the rest
+(negative=5, alpha=0.025, min_alpha=1e-4, sample=1e-3, ns exponent 0.75).
+
+Multi-GPU: every rank trains a full replica on its shard of the walks
+(shard = contiguous start positions, as for the walk itself) and the two tables are
+all-reduced over RCCL at sync points inside the epoch and at its end; the learning-rate
+schedule is driven by the GLOBAL sentence count.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_WORDS_IN_BATCH = 10000  # gensim: words per job; alpha is stepped once per job
+LUT_BITS = 20
+
+
+def vocab_tables(counts, sample=1e-3, ns_exponent=0.75):
+    """counts int64[N] (occurrences of each dense id in the corpus; 0 = not in the vocabulary)
+    -> (sample_int uint32[N] or None, cum_table uint32[N]).
+
+    gensim scale_vocab: threshold = sample * total; keep probability
+    (sqrt(v/threshold) + 1) * (threshold/v) capped at 1, stored as round(p * 2^32).
+    gensim make_cum_table: cum_table[i] = round(sum_{k<=i} count_k^0.75 / Z * (2^31 - 1)).
+    """
+    counts = np.asarray(counts, dtype=np.int64)
+    v = counts.astype(np.float64)
+    total = float(counts.sum())
+    if total <= 0:
+        raise ValueError("empty corpus")
+    if not sample:
+        sample_int = None
+    else:
+        thr = sample * total if sample < 1.0 else float(int(sample * (3 + np.sqrt(5)) / 2))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            wp = (np.sqrt(v / thr) + 1.0) * (thr / v)
+        wp = np.where(counts > 0, np.minimum(wp, 1.0), 1.0)
+        sample_int = np.minimum(np.round(wp * 2.0**32), 2.0**32 - 1).astype(np.uint32)
+    powc = v ** ns_exponent
+    cum = np.cumsum(powc)
+    z = cum[-1]
+    domain = 2**31 - 1
+    cum_table = np.round(cum / z * domain).astype(np.int64)
+    last_nz = int(np.nonzero(counts)[0][-1])
+    cum_table[last_nz:] = domain  # gensim asserts cum_table[-1] == domain
+    return sample_int, cum_table.astype(np.uint32)
+
+
+def _row_stride(dim):
+    for s in (64, 128, 256, 512):
+        if dim <= s:
+            return s
+    raise ValueError("dimensions > 512 are not supported by the wave-per-pair kernel")
+
+
+class SgnsModel:
+    """Embedding tables + vocabulary statistics of one training run, on one device."""
+
+    def __init__(self, n_words, dim=128, window=10, negative=5, alpha=0.025, min_alpha=1e-4, sample=1e-3,
+                 seed=1, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("n2v_hip: no GPU visible; the SGNS trainer has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.n_words, self.dim = int(n_words), int(dim)
+        self.stride = _row_stride(self.dim)
+        self.window, self.negative = int(window), int(negative)
+        self.alpha, self.min_alpha, self.sample, self.seed = float(alpha), float(min_alpha), sample, int(seed)
+        d = self.device
+        self.syn0 = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
+        self.syn1neg = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
+        self.pair_count = torch.zeros(1, dtype=torch.int64, device=d)
+        self.counts = None
+        self.sample_int = self.cum_table = self.lut = None
+        self.reset_weights()
+
+    def _stream(self):
+        return _lib.stream_ptr(self.device)
+
+    def reset_weights(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.n2v_sgns_init(_lib.ptr(self.syn0), _lib.ptr(self.syn1neg), self.n_words, self.dim,
+                                              self.stride, self.seed & (2**64 - 1), self._stream()))
+
+    def build_vocab(self, walks=None, counts=None):
+        """Word counts from a device corpus (int32 [W, L], -1 padded) or given directly."""
+        d = self.device
+        if counts is None:
+            flat = walks.reshape(-1)
+            flat = flat[flat >= 0].long()
+            counts_t = torch.bincount(flat, minlength=self.n_words)
+        else:
+            counts_t = torch.as_tensor(counts, dtype=torch.int64, device=d)
+        self.counts = counts_t.cpu().numpy()
+        sample_int, cum = vocab_tables(self.counts, self.sample)
+        self.sample_int = None if sample_int is None else torch.from_numpy(sample_int.view(np.int32)).to(d)
+        self.cum_table = torch.from_numpy(cum.view(np.int32)).to(d)
+        self.lut = torch.empty((1 << LUT_BITS) + 1, dtype=torch.int32, device=d)
+        with torch.cuda.device(d):
+            _lib.check(self.lib.n2v_build_neg_lut(_lib.ptr(self.cum_table), self.n_words, LUT_BITS,
+                                                  _lib.ptr(self.lut), self._stream()))
+
+    def train_pass(self, walks, lens, sentences_base, sentences_total, walk_id_base, sentences_step=1,
+                   max_blocks=0):
+        """One kernel launch over `walks` (device int32 [n, L]); asynchronous."""
+        assert walks.dtype == torch.int32 and walks.is_contiguous() and walks.device == self.device
+        n, L = int(walks.shape[0]), int(walks.shape[1])
+        if n == 0:
+            return
+        alpha_batch = max(1, MAX_WORDS_IN_BATCH // L)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.n2v_sgns_train(
+                _lib.ptr(walks), _lib.ptr(lens), n, L, _lib.ptr(self.syn0), _lib.ptr(self.syn1neg), self.n_words,
+                self.dim, self.stride, self.window, self.negative, _lib.ptr(self.sample_int),
+                _lib.ptr(self.cum_table), _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha,
+                int(sentences_base), int(sentences_step), int(sentences_total), alpha_batch,
+                self.seed & (2**64 - 1),
+                int(walk_id_base), _lib.ptr(self.pair_count), int(max_blocks), self._stream()))
+
+    def pairs_trained(self):
+        return int(self.pair_count.item())
+
+    def vectors(self):
+        """syn0 without the padding columns (device view)."""
+        return self.syn0[:, :self.dim]
+
+
+class _ProcessGroupComm:
+    """torch.distributed all-reduce (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+def shard_bounds(n_items, world, rank):
+    """Contiguous shard [begin, end) of n_items for `rank` (as src/main_link.py:261-264 splits
+    start nodes among its pool workers)."""
+    per = -(-n_items // world)
+    b = min(rank * per, n_items)
+    return b, min(b + per, n_items)
+
+
+def merge_replicas(tables, bases, comm, mode):
+    """Combine the replicas' tables in place at a sync point.
+    mode 'avg'   : mean of the replicas.
+    mode 'delta' : base + sum of every replica's change since the last sync (what a shared
+                   Hogwild table would have received); `bases` holds the last merged copy."""
+    for t, b in zip(tables, bases):
+        comm.all_reduce_sum(t)
+        if mode == "avg":
+            t.div_(comm.world)
+        else:
+            t.sub_(b, alpha=comm.world - 1)
+        if b is not None:
+            b.copy_(t)
+
+
+def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch=16,
+          merge="delta"):
+    """Train `epochs` passes over this rank's walks.  With a communicator, replicas are merged
+    `syncs_per_epoch` times per epoch (the last one at the epoch boundary)."""
+    n_local = int(walks.shape[0])
+    if n_walks_global is None:
+        n_walks_global = n_local
+    total = epochs * n_walks_global
+    world = comm.world if comm is not None else 1
+    bases = None
+    if world > 1:
+        bases = [model.syn0.clone(), model.syn1neg.clone()] if merge == "delta" else [None, None]
+        n_chunks = max(1, int(syncs_per_epoch))
+    else:
+        n_chunks = 1
+    for ep in range(epochs):
+        for c in range(n_chunks):
+            b, e = shard_bounds(n_local, n_chunks, c)
+            if e > b:
+                # all replicas advance together: `b` local sentences = b * world global ones
+                model.train_pass(walks[b:e], None if lens is None else lens[b:e],
+                                 sentences_base=ep * n_walks_global + b * world, sentences_step=world,
+                                 sentences_total=total,
+                                 walk_id_base=ep * n_walks_global + shard_offset + b)
+            if world > 1:
+                merge_replicas([model.syn0, model.syn1neg], bases, comm, merge)
+    return model
+
+
+# --------------------------------------------------------------------------- gensim-like results
+class _VocabEntry:
+    __slots__ = ("index", "count")
+
+    def __init__(self, index, count):
+        self.index, self.count = index, count
+
+
+class KeyedVectors:
+    """The part of gensim's KeyedVectors the reference's consumers use
+    (src/main_link.py:43-61,130,358-365): ``wv[str(id)]``, ``wv.similarity(a, b)``,
+    ``wv.vocab`` (keys are str(id)), ``save_word2vec_format(path)``; words are ordered by
+    descending corpus count like gensim's sorted vocabulary."""
+
+    def __init__(self, labels, counts, vectors):
+        order = np.argsort(-counts, kind="stable")
+        order = order[counts[order] > 0]
+        self.index2word = [str(int(labels[i])) for i in order]
+        self.syn0 = np.ascontiguousarray(vectors[order], dtype=np.float32)
+        self.vectors = self.syn0
+        self.vocab = {w: _VocabEntry(i, int(counts[order[i]])) for i, w in enumerate(self.index2word)}
+        self.vector_size = self.syn0.shape[1] if self.syn0.ndim == 2 else 0
+
+    def __getitem__(self, word):
+        if isinstance(word, (list, tuple, np.ndarray)):
+            return np.vstack([self[w] for w in word])
+        return self.syn0[self.vocab[word].index]
+
+    def __contains__(self, word):
+        return word in self.vocab
+
+    def similarity(self, w1, w2):
+        a, b = self[w1], self[w2]
+        return float(np.dot(a / np.linalg.norm(a), b / np.linalg.norm(b)))
+
+    def save_word2vec_format(self, fname):
+        with open(fname, "w") as f:
+            f.write("%d %d\n" % (len(self.index2word), self.vector_size))
+            for w, row in zip(self.index2word, self.syn0):
+                f.write("%s %s\n" % (w, " ".join("%f" % x for x in row)))
+
+
+class Word2VecResult:
+    """What ``learn_embeddings`` returns in src/main.py:82-90 (the model; ``.wv`` is what
+    src/main_link.py:36-41 returns)."""
+
+    def __init__(self, wv, model, pairs):
+        self.wv = wv
+        self.sgns = model
+        self.pairs_trained = pairs
+
+    def __getitem__(self, word):
+        return self.wv[word]
+
+    def save_word2vec_format(self, fname):
+        self.wv.save_word2vec_format(fname)
+
+
+def smoke_check(graph, corpus):
+    """One tiny SGNS pass on the walks of __graft_entry__.smoke(); checks that training
+    moved the tables, produced finite values and counted the pairs the windows imply."""
+    csr = graph._csr
+    m = SgnsModel(csr.n_nodes, dim=128, window=5, negative=5, sample=0, seed=7, device=corpus.walks.device)
+    m.build_vocab(corpus.walks)
+    before = m.syn0.clone()
+    train(m, corpus.walks, corpus.lens, epochs=1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(m.syn0).all() and torch.isfinite(m.syn1neg).all()
+    assert (m.syn0 != before).any() and (m.syn1neg != 0).any()
+    assert (m.syn0[:, m.dim:] == 0).all()
+    n_pairs = m.pairs_trained()
+    L = corpus.walks.shape[1]
+    W = corpus.walks.shape[0]
+    assert 0 < n_pairs <= W * L * 2 * 5, n_pairs
+    print("smoke: SGNS pass trained %d pairs" % n_pairs)

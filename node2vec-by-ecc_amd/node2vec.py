@@ -94,6 +94,25 @@ class WalkCorpus:
         return "WalkCorpus(%d walks x %d)" % tuple(self.walks.shape)
 
 
+def as_corpus(walks, device=None):
+    """A WalkCorpus as is; a list of lists of node labels (e.g. walks reloaded from a walk
+    file, src/main_link.py:345-349) is densified and moved to the device."""
+    if isinstance(walks, WalkCorpus):
+        return walks
+    if not torch.cuda.is_available():
+        raise RuntimeError("n2v_hip: no GPU visible; there is no CPU fallback")
+    rows = [np.asarray(list(w), dtype=np.int64) for w in walks]
+    L = max([len(r) for r in rows] + [1])
+    labels = np.unique(np.concatenate(rows)) if rows else np.zeros(0, dtype=np.int64)
+    dense = np.full((len(rows), L), -1, dtype=np.int32)
+    lens = np.zeros(len(rows), dtype=np.int32)
+    for i, r in enumerate(rows):
+        dense[i, :len(r)] = np.searchsorted(labels, r)
+        lens[i] = len(r)
+    d = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    return WalkCorpus(torch.from_numpy(dense).to(d), torch.from_numpy(lens).to(d), labels)
+
+
 class _AliasNodes:
     """Dict-like view of the node tables: ``alias_nodes[node] -> (J, q)``."""
 

@@ -125,3 +125,33 @@ class CsrOracle:
             raise ZeroDivisionError("float division by zero")
         assert n >= 0
         return walks, lens, int(n)
+
+
+# ---------------------------------------------------------------------------- SGNS (sgns_oracle.c)
+def randint_fill(seed, high, n):
+    out = np.empty(n, dtype=np.int64)
+    lib().orc_randint_fill(C.c_uint32(seed), C.c_uint32(high), C.c_int64(n), _p(out))
+    return out
+
+
+def sgns_init(n_words, dim, stride, seed):
+    syn0 = np.empty((n_words, stride), dtype=np.float32)
+    syn1 = np.empty((n_words, stride), dtype=np.float32)
+    lib().orc_sgns_init(_p(syn0), _p(syn1), C.c_int64(n_words), C.c_int32(dim), C.c_int32(stride), C.c_uint64(seed))
+    return syn0, syn1
+
+
+def sgns_train(walks, lens, syn0, syn1neg, dim, window, negative, sample_int, cum_table, alpha=0.025,
+               min_alpha=1e-4, epochs=1, seed=1, n_threads=1):
+    """In-place training of syn0/syn1neg (float32 [n_words, stride]); returns pairs trained."""
+    walks = np.ascontiguousarray(walks, dtype=np.int32)
+    lens = None if lens is None else np.ascontiguousarray(lens, dtype=np.int32)
+    assert syn0.dtype == np.float32 and syn0.flags.c_contiguous and syn1neg.flags.c_contiguous
+    si = None if sample_int is None else np.ascontiguousarray(sample_int, dtype=np.uint32)
+    ct = np.ascontiguousarray(cum_table, dtype=np.uint32)
+    n = lib().orc_sgns_train(
+        _p(walks), _p(lens), C.c_int64(walks.shape[0]), C.c_int32(walks.shape[1]), _p(syn0), _p(syn1neg),
+        C.c_int64(syn0.shape[0]), C.c_int32(dim), C.c_int32(syn0.shape[1]), C.c_int32(window), C.c_int32(negative),
+        _p(si), _p(ct), C.c_float(alpha), C.c_float(min_alpha), C.c_int32(epochs), C.c_uint32(seed),
+        C.c_int32(n_threads))
+    return int(n)

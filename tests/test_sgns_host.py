@@ -1,0 +1,101 @@
+"""CPU tests of the SGNS host logic: vocabulary statistics vs the oracle's word-by-word
+restatement, shard arithmetic, replica merging over gloo (world_size 2), and the device
+link-prediction evaluator (run on CPU tensors) vs scikit-learn."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT
+
+
+def test_vocab_tables_match_oracle_restatement():
+    from n2v_hip import sgns
+    from oracle import sgns_oracle
+    rs = np.random.RandomState(0)
+    for trial in range(5):
+        counts = (rs.pareto(1.1, 2000) * 20).astype(np.int64)
+        counts[rs.randint(0, 2000, 100)] = 0
+        counts[0] = 10**6
+        for sample in (1e-3, 1e-5, 0):
+            a_si, a_cum = sgns.vocab_tables(counts, sample)
+            b_si, b_cum = sgns_oracle.vocab_tables(counts, sample)
+            assert (a_si is None) == (b_si is None)
+            if a_si is not None:
+                assert np.array_equal(a_si, b_si)
+            assert np.array_equal(a_cum, b_cum)
+
+
+def test_shard_bounds_cover_exactly():
+    from n2v_hip.sgns import shard_bounds
+    for n in (0, 1, 7, 1000, 1000003):
+        for world in (1, 2, 3, 8):
+            got = [shard_bounds(n, world, r) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+            assert all(e >= b for b, e in got)
+
+
+def test_linkpred_metrics_match_sklearn():
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    from n2v_hip import linkpred
+    rs = np.random.RandomState(0)
+    for trial in range(5):
+        pos = np.round(rs.normal(0.3, 1, 400), 1 if trial % 2 else 6)   # with and without ties
+        neg = np.round(rs.normal(0.0, 1, 700), 1 if trial % 2 else 6)
+        y = np.r_[np.ones(400), np.zeros(700)]
+        s = np.r_[pos, neg]
+        a = linkpred.roc_auc(torch.from_numpy(pos), torch.from_numpy(neg))
+        b = linkpred.average_precision(torch.from_numpy(pos), torch.from_numpy(neg))
+        assert abs(a - roc_auc_score(y, s)) < 1e-12
+        assert abs(b - average_precision_score(y, s)) < 1e-12
+    v = torch.from_numpy(rs.normal(size=(50, 16)).astype(np.float32))
+    pairs = torch.from_numpy(rs.randint(0, 50, size=(30, 2)))
+    got = linkpred.cosine_scores(v, pairs).numpy()
+    want = [float(np.dot(v[a] / np.linalg.norm(v[a]), v[b] / np.linalg.norm(v[b]))) for a, b in pairs.tolist()]
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "node2vec-by-ecc_amd"))
+import torch, torch.distributed as dist
+from n2v_hip import sgns
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+comm = sgns._ProcessGroupComm()
+assert comm.world == 2
+for mode in ("avg", "delta"):
+    base0 = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    t = base0.clone()
+    bases = [base0.clone()]
+    t[rank] += 1.0 + rank            # each replica changes its own row ...
+    t[2] += 10.0 * (rank + 1)        # ... and both change row 2
+    sgns.merge_replicas([t], bases if mode == "delta" else [None], comm, mode)
+    want = base0.clone()
+    if mode == "avg":
+        want[0] += 0.5; want[1] += 1.0; want[2] += 15.0
+    else:
+        want[0] += 1.0; want[1] += 2.0; want[2] += 30.0
+    assert torch.allclose(t, want), (mode, t, want)
+    if mode == "delta":
+        assert torch.equal(bases[0], t)
+b, e = sgns.shard_bounds(101, 2, rank)
+tot = torch.tensor([e - b]); dist.all_reduce(tot); assert int(tot) == 101
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_replica_merge_over_gloo_world2(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER % {"root": ROOT, "port": port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
