@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Benchmark of the node2vec hot path on MI355X: 2nd-order walk + SGNS (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: `rounds` walks of length 80 from every
+start vertex of this rank's shard (walk kernel), then one SGNS pass over those walks (SGNS
+kernel; with N > 1 the replicas' tables are all-reduced over RCCL inside the pass).  Inputs
+(CSR, alias tables, embedding tables, vocabulary statistics) are resident in HBM before the
+timed region.  Scaling is WEAK: every rank walks its start-vertex shard for rounds*N rounds,
+so per-GPU work is the same at every N and the corpus grows with N.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "node2vec-by-ecc_amd"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+WALK_BYTES_PER_STEP = 36     # table-driven walk, 32 B read + 4 B write
+SGNS_BYTES_PER_PAIR_128 = 7168  # d=128, 1 positive + 5 negatives, fp32 read+write
+
+CONFIGS = {
+    # name: (graph key, p, q, description)
+    "C2": ("C2", 1.0, 1.0, "C2: Erdos-Renyi 100k nodes / 1M edges, p=q=1, d=128"),
+    "C3": ("C3", 0.25, 4.0, "C3: power-law (Barabasi-Albert) 1M nodes / 10M edges, p=0.25 q=4, d=128"),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baselines(cg, p, q, walks_sample, lens_sample, counts, dim, budget_s=12.0):
+    """CPU restatement of the reference path timed on this host (rank 0 only, bounded sample).
+    Primary: pure-Python restatement of src/node2vec.py (what the reference runs).  Extra: the
+    oracle's C port (walk, 1 thread) and its SGNS restatement (1 thread and all cores)."""
+    from oracle import c_oracle, sgns_oracle
+    from oracle import n2v_oracle as orc
+    out = {}
+    G = orc.CsrBackedGraph(cg.labels, cg.row_ptr, cg.col, cg.w, cg.start_order, cg.directed)
+    o = orc.Node2VecOracle(G, cg.directed, p, q)
+    nodes = G.nodes[:2000]
+    rs = np.random.RandomState(123)
+    t0 = time.perf_counter()
+    steps = 0
+    done = 0
+    for node in nodes:  # src/node2vec.py:97-111 order, one round
+        w = o.node2vec_walk(80, node, rs.random_sample, on_the_fly=True)
+        steps += len(w) - 1
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {
+        "value": steps / dt, "unit": "walk-steps/s", "cores": 1, "kind": "port",
+        "sample": "first %d start vertices x 1 round x L=80 of the same graph; pure-Python restatement of "
+                  "src/node2vec.py (on-the-fly tables as src/settings.py:18, per-step sorted neighbours, two "
+                  "MT19937 draws per step); %.1f s" % (done, dt)}
+    extra = {"host_cpus": os.cpu_count()}
+    # C port of the walk (table rebuilt per step), 1 thread, 20000 starts
+    co = c_oracle.CsrOracle(cg.row_ptr, cg.col, cg.w, p, q)
+    t0 = time.perf_counter()
+    ns = min(20000, cg.n_nodes)
+    _, l, _ = co.walk(cg.start_order[:ns], 1, 80, mode="mt", seed=1, on_the_fly=True)
+    dt = time.perf_counter() - t0
+    extra["walk_c_port_on_the_fly"] = {"value": float((l - 1).sum()) / dt, "unit": "walk-steps/s", "cores": 1,
+                                       "sample": "%d start vertices x 1 round" % ns}
+    # SGNS restatement on a sample of the GPU-generated walks
+    si, cum = sgns_oracle.vocab_tables(counts, 1e-3) if cg.n_nodes <= 200000 else (None, None)
+    if si is None:
+        from n2v_hip import sgns as _ps  # same statistics, vectorised (checked equal in tests/)
+        si, cum = _ps.vocab_tables(counts, 1e-3)
+    stride = 128 if dim <= 128 else 256
+    for threads, nw in ((1, 2000), (os.cpu_count() or 1, 16000)):
+        nw = min(nw, walks_sample.shape[0])
+        syn0, syn1 = c_oracle.sgns_init(cg.n_nodes, dim, stride, 1)
+        t0 = time.perf_counter()
+        pairs = c_oracle.sgns_train(walks_sample[:nw], lens_sample[:nw], syn0, syn1, dim, 10, 5, si, cum,
+                                    n_threads=threads)
+        dt = time.perf_counter() - t0
+        extra["sgns_c_port_%s" % ("1thread" if threads == 1 else "allcores")] = {
+            "value": pairs / dt, "unit": "pair-updates/s", "cores": threads, "sample": "%d walks of the batch" % nw}
+        del syn0, syn1
+    out["cpu_baseline_extra"] = extra
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--rounds", type=int, default=10, help="walks per start vertex per step and per GPU (BASELINE: 10)")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--syncs", type=int, default=16, help="replica merges per SGNS pass when N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback)")
+    dev = torch.device("cuda:%d" % (local_rank % ndev))
+    torch.cuda.set_device(dev)
+    comm = None
+    host_staged = False
+    if world > 1:
+        import torch.distributed as dist
+        backend = args.backend
+        if backend == "auto":
+            backend = "nccl" if ndev >= world else "gloo"   # gloo = rehearsal on a box with fewer GPUs
+        host_staged = backend == "gloo"
+        dist.init_process_group(backend, init_method="env://", rank=rank, world_size=world,
+                                device_id=None if host_staged else dev)
+    import node2vec
+    from n2v_hip import sgns, synth
+
+    if world > 1:
+        class Comm(sgns._ProcessGroupComm):
+            def all_reduce_sum(self, t):
+                if host_staged:
+                    h = t.cpu()
+                    self.dist.all_reduce(h)
+                    t.copy_(h)
+                else:
+                    self.dist.all_reduce(t)
+        comm = Comm()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    gkey, p, q, desc = CONFIGS[args.config]
+    L, window, negative = 80, 10, 5
+    t0 = time.perf_counter()
+    cg, info = synth.make_config_graph(gkey)
+    t_graph = time.perf_counter() - t0
+    g = node2vec.Graph.from_csr(cg, p, q, device=dev, rng="philox", seed=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.preprocess_transition_probs()
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter() - t0
+    eng = g._engine
+    if rank == 0:
+        log("[bench] %s: graph %.1fs, preprocess %.2fs (%d alias slots, %.1f GB)" % (
+            args.config, t_graph, t_pre, eng.total_slots, eng.total_slots * 16 / 1e9))
+
+    N = cg.n_nodes
+    pos_begin, pos_end = sgns.shard_bounds(N, world, rank)
+    pos_count = pos_end - pos_begin
+    rounds_total = args.rounds * world          # weak scaling: per-GPU walks = rounds * N at every world size
+    n_local = pos_count * rounds_total
+    n_global = N * rounds_total
+    walks = torch.empty((n_local, L), dtype=torch.int32, device=dev)
+    lens = torch.empty(n_local, dtype=torch.int32, device=dev)
+
+    def walk_step(step_no):
+        eng.walk(eng.start_order, rounds_total, L, rng="philox", seed=1000 + step_no, pos_begin=pos_begin,
+                 pos_count=pos_count, out=(walks, lens))
+
+    # vocabulary statistics (gensim build_vocab) from one batch of walks, identical on all ranks
+    walk_step(-1)
+    counts = torch.zeros(N, dtype=torch.int64, device=dev)
+    for b in range(0, n_local, 1 << 20):   # chunked: keeps the int64 temporaries small
+        flat = walks[b:b + (1 << 20)].reshape(-1)
+        counts += torch.bincount(flat[flat >= 0].long(), minlength=N)
+    if world > 1:
+        comm.all_reduce_sum(counts)
+    model = sgns.SgnsModel(N, dim=args.dim, window=window, negative=negative, seed=1, device=dev)
+    model.build_vocab(counts=counts)
+    shard_offset = pos_begin * rounds_total
+
+    def sgns_step(step_no):
+        sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
+                   syncs_per_epoch=args.syncs)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for s in range(args.warmup):
+        walk_step(s)
+        sgns_step(s)
+    torch.cuda.synchronize()
+    model.pair_count.zero_()
+    steps_done = torch.zeros(1, dtype=torch.int64, device=dev)
+    marks = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        walk_step(args.warmup + s)
+        e1.record()
+        steps_done += (lens.long() - 1).clamp_min(0).sum()
+        e1b = ev()
+        e1b.record()
+        sgns_step(args.warmup + s)
+        e2.record()
+        marks.append((e0, e1, e1b, e2))
+    torch.cuda.synchronize()
+    barrier()
+    t_total = time.perf_counter() - t0
+    t_walk = sum(a.elapsed_time(b) for a, b, _, _ in marks) / 1e3
+    t_sgns = sum(c.elapsed_time(d) for _, _, c, d in marks) / 1e3
+
+    stats = torch.tensor([t_total, t_walk, t_sgns], dtype=torch.float64, device=dev)
+    sums = torch.tensor([float(steps_done.item()), float(model.pairs_trained())], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        if host_staged:
+            stats, sums = stats.cpu(), sums.cpu()
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    t_total, t_walk, t_sgns = [float(x) for x in stats.tolist()]
+    steps_all, pairs_all = [float(x) for x in sums.tolist()]
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    K = args.steps
+    walk_rate = steps_all / t_walk
+    pair_rate = pairs_all / t_sgns
+    stride_scale = model.stride / 128.0
+    # per-launch figures of THIS rank (rank 0): algorithmic bytes / mean launch duration
+    walk_launch_s = sum(a.elapsed_time(b) for a, b, _, _ in marks) / 1e3 / K
+    sgns_launch_s = sum(c.elapsed_time(d) for _, _, c, d in marks) / 1e3 / K
+    walk_bytes_launch = float(steps_done.item()) / K * WALK_BYTES_PER_STEP
+    sgns_bytes_launch = float(model.pairs_trained()) / K * SGNS_BYTES_PER_PAIR_128 * stride_scale
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get("%s_n1" % args.config) if world == 1 else None
+        except Exception:
+            traffic = None
+    result = {
+        "metric": "walk-steps/s",
+        "value": walk_rate,
+        "unit": "walk-steps/s",
+        "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": t_total / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 alias draw / int32 ids (walk); f32 (SGNS)",
+        "data": "synthetic",
+        "config": {"workload": desc, "walk_length": L, "rounds_per_gpu_per_step": args.rounds,
+                   "walks_per_step_global": n_global, "window": window, "negative": negative, "dim": args.dim,
+                   "rng": "philox4x32-10 in-kernel (walk rule bit-identical to the reference under given uniforms)",
+                   "sharding": "start-vertex shards, %d replica merges (RCCL all-reduce) per SGNS pass" % args.syncs
+                   if world > 1 else "single GPU", **info},
+        "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
+                 "pairs_per_step_global": pairs_all / K, "seconds_per_step": t_sgns / K},
+        "walk": {"steps_per_step_global": steps_all / K, "seconds_per_step": t_walk / K},
+        "preprocess_seconds": t_pre, "alias_slots": eng.total_slots,
+        # dominant kernel by time: sgns_kernel
+        "roofline": {"kernel": "sgns_kernel", "bound": "hbm", "achieved": sgns_bytes_launch / sgns_launch_s / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": sgns_bytes_launch / sgns_launch_s / 1e9 / HBM_PEAK_GBS,
+                     "traffic": (traffic or {}).get("sgns_kernel"),
+                     "algorithmic_bytes_per_unit": SGNS_BYTES_PER_PAIR_128 * stride_scale, "unit_name": "pair",
+                     "launch_ms": sgns_launch_s * 1e3},
+        "roofline_walk": {"kernel": "walk_kernel", "bound": "hbm", "achieved": walk_bytes_launch / walk_launch_s / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": walk_bytes_launch / walk_launch_s / 1e9 / HBM_PEAK_GBS,
+                          "traffic": (traffic or {}).get("walk_kernel"),
+                          "algorithmic_bytes_per_unit": WALK_BYTES_PER_STEP, "unit_name": "walk step",
+                          "launch_ms": walk_launch_s * 1e3},
+    }
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        ns = min(16000, n_local)
+        result.update(cpu_baselines(cg, p, q, walks[:ns].cpu().numpy(), lens[:ns].cpu().numpy(),
+                                    model.counts, args.dim))
+        log("[bench] cpu baselines took %.1fs" % (time.perf_counter() - t0))
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

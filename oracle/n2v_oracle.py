@@ -249,3 +249,47 @@ def philox_step_uniforms(seed, walk, step):
     u1 = ((r[0] >> 5) * 67108864.0 + (r[1] >> 6)) / 9007199254740992.0
     u2 = ((r[2] >> 5) * 67108864.0 + (r[3] >> 6)) / 9007199254740992.0
     return u1, u2
+
+
+# --------------------------------------------------------------------------- CSR-backed graph
+class _LazyAdj(dict):
+    """adj[node] -> {neighbour: weight}, materialised from CSR on first touch."""
+
+    def __init__(self, g):
+        super().__init__()
+        self._g = g
+
+    def __missing__(self, node):
+        g = self._g
+        d = int(np.searchsorted(g.labels, node))
+        if d >= len(g.labels) or g.labels[d] != node:
+            raise KeyError(node)
+        b, e = int(g.row_ptr[d]), int(g.row_ptr[d + 1])
+        nb = g.labels[g.col[b:e]].tolist()
+        ws = [1] * (e - b) if g.w is None else g.w[b:e].tolist()
+        row = dict(zip(nb, ws))
+        self[node] = row
+        return row
+
+
+class CsrBackedGraph:
+    """Same interface as OracleGraph, for graphs too large to hold as dict-of-dicts up front
+    (the cpu_baseline leg of bench.py walks a bounded sample of a 10^6-node graph): rows are
+    turned into the reference's {nbr: weight} dicts only when a walk touches them, so the
+    per-step cost structure of the pure-Python walk (sorted(), dict probes, per-step
+    alias_setup) is the reference's."""
+
+    def __init__(self, labels, row_ptr, col, w, start_order, directed):
+        self.labels, self.row_ptr, self.col, self.w = labels, row_ptr, col, w
+        self.directed = bool(directed)
+        self.nodes = labels[start_order].tolist()
+        self.adj = _LazyAdj(self)
+
+    def neighbors(self, v):
+        return self.adj[v].keys()
+
+    def has_edge(self, u, v):
+        try:
+            return v in self.adj[u]
+        except KeyError:
+            return False

@@ -192,7 +192,7 @@ def test_link_prediction_auc_within_band_of_cpu_comparator(torch_cuda):
     auc_cpu, ap_cpu = sgns_oracle.roc_score(vec, te.tolist(), neg.tolist())
     # the device evaluator agrees with sklearn on the CPU vectors
     auc_chk, ap_chk = linkpred.get_roc_score(torch.from_numpy(syn0).to("cuda:0"), te_d, neg_d)
-    assert abs(auc_chk - auc_cpu) < 1e-9 and abs(ap_chk - ap_cpu) < 1e-6
+    assert abs(auc_chk - auc_cpu) < 1e-6 and abs(ap_chk - ap_cpu) < 1e-5  # fp32 cosine on device vs fp64 numpy
     print("AUC gpu %.5f cpu %.5f | AP gpu %.5f cpu %.5f | pairs gpu %d cpu %d" % (
         auc_gpu, auc_cpu, ap_gpu, ap_cpu, m.pairs_trained(), pairs_cpu))
     assert abs(m.pairs_trained() - pairs_cpu) / pairs_cpu < 0.01
