@@ -143,14 +143,22 @@ int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bi
  * advancing together, 1 on a single GPU).  seed/walk_id_base key the
  * per-sentence random streams (sub-sampling, window shrink, negative draws).
  * pair_count (may be NULL): incremented by the number of (centre, context) pairs trained.
+ * update_mode: how the racing wavefronts share rows (gensim's workers race the same way):
+ *   N2V_SGNS_PLAIN  plain loads/stores (per-XCD L2 copies; fastest, loses updates),
+ *   N2V_SGNS_AGENT  agent-scope loads and stores (one copy at the memory side),
+ *   N2V_SGNS_ATOMIC agent-scope loads + float atomic adds (no update is lost).
  * max_blocks <= 0 picks the default grid (2048 workgroups of 4 wavefronts).              */
+#define N2V_SGNS_PLAIN 0
+#define N2V_SGNS_AGENT 1
+#define N2V_SGNS_ATOMIC 2
 int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
                    float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
                    int32_t window, int32_t negative, const uint32_t* sample_int,
                    const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
                    float min_alpha, int64_t sentences_base, int64_t sentences_step,
                    int64_t sentences_total, int64_t alpha_batch, uint64_t seed, uint64_t walk_id_base,
-                   unsigned long long* pair_count, int32_t max_blocks, void* stream);
+                   unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
+                   void* stream);
 
 #ifdef __cplusplus
 }

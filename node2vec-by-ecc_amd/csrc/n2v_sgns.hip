@@ -122,42 +122,108 @@ struct Row {
     float v[VPL];
 };
 
+// How rows are shared between wavefronts (all of them race, as gensim's Hogwild threads do):
+//  kPlain  : plain loads and stores.  Lines live in the issuing XCD's write-back L2, which is
+//            not coherent with the other seven: an XCD keeps training on its own copy of a hot
+//            row and whole-row write-backs overwrite each other.  Fastest; loses updates.
+//  kAgent  : agent-scope (sc1) loads and stores — every access goes to the memory side
+//            (Infinity Cache / HBM), so all wavefronts see one copy; a read-modify-write can
+//            still lose a concurrent update.
+//  kAtomic : agent-scope loads, and every update applied as a float atomic add at the memory
+//            side (global_atomic_add_f32, 256 contiguous bytes per wave-instruction): no
+//            update is ever lost.  Default.
+enum : int { kPlain = 0, kAgent = 1, kAtomic = 2 };
+
+template <int MODE>
+__device__ __forceinline__ float2 ld2(const float* p) {
+    if constexpr (MODE == kPlain) {
+        return *reinterpret_cast<const float2*>(p);
+    } else {
+        const uint64_t b = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        return make_float2(__builtin_bit_cast(float, (uint32_t)b), __builtin_bit_cast(float, (uint32_t)(b >> 32)));
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void st2(float* p, float x, float y) {
+    if constexpr (MODE == kPlain) {
+        *reinterpret_cast<float2*>(p) = make_float2(x, y);
+    } else {
+        const uint64_t b = (uint64_t)__builtin_bit_cast(uint32_t, x) | ((uint64_t)__builtin_bit_cast(uint32_t, y) << 32);
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Lane layout of a row: VPL <= 2: lane owns VPL consecutive floats; VPL >= 4: 1-KiB chunks of
+// the row, 4 floats per lane in each (every wave-instruction touches contiguous bytes).
 template <int VPL>
+__device__ __forceinline__ int lane_off(int lane) { return VPL <= 2 ? lane * VPL : lane * 4; }
+
+template <int VPL, int MODE>
 __device__ __forceinline__ Row<VPL> load_row(const float* base, int64_t row, int stride, int lane) {
     Row<VPL> r;
-    // VPL <= 2: lane owns VPL consecutive floats; VPL >= 4: 1-KiB chunks, 4 floats per lane each
-    const float* p = base + row * stride + (VPL <= 2 ? lane * VPL : lane * 4);
+    if constexpr (MODE == kAtomic) {
+        // element i of the lane = float i*64 + lane: each wave-instruction covers 256 contiguous
+        // bytes, the shape the memory-side float atomics (add_row) run at full rate for
+        const float* q = base + row * stride + lane;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) r.v[i] = __hip_atomic_load(q + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return r;
+    }
+    const float* p = base + row * stride + lane_off<VPL>(lane);
     if constexpr (VPL == 1) {
-        r.v[0] = *p;
+        if constexpr (MODE == kPlain) r.v[0] = *p;
+        else r.v[0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if constexpr (VPL == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(p);
+        const float2 t = ld2<MODE>(p);
         r.v[0] = t.x; r.v[1] = t.y;
     } else {
 #pragma unroll
         for (int i = 0; i < VPL; i += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p + i * 64);
-            r.v[i] = t.x; r.v[i + 1] = t.y; r.v[i + 2] = t.z; r.v[i + 3] = t.w;
+            if constexpr (MODE == kPlain) {
+                const float4 t = *reinterpret_cast<const float4*>(p + i * 64);
+                r.v[i] = t.x; r.v[i + 1] = t.y; r.v[i + 2] = t.z; r.v[i + 3] = t.w;
+            } else {
+                const float2 t0 = ld2<MODE>(p + i * 64), t1 = ld2<MODE>(p + i * 64 + 2);
+                r.v[i] = t0.x; r.v[i + 1] = t0.y; r.v[i + 2] = t1.x; r.v[i + 3] = t1.y;
+            }
         }
     }
     return r;
 }
 
-template <int VPL>
+template <int VPL, int MODE>
 __device__ __forceinline__ void store_row(float* base, int64_t row, int stride, int lane, const Row<VPL>& r) {
-    float* p = base + row * stride + (VPL <= 2 ? lane * VPL : lane * 4);
+    float* p = base + row * stride + lane_off<VPL>(lane);
     if constexpr (VPL == 1) {
-        *p = r.v[0];
+        if constexpr (MODE == kPlain) *p = r.v[0];
+        else __hip_atomic_store(p, r.v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if constexpr (VPL == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
+        st2<MODE>(p, r.v[0], r.v[1]);
     } else {
 #pragma unroll
-        for (int i = 0; i < VPL; i += 4)
-            *reinterpret_cast<float4*>(p + i * 64) = make_float4(r.v[i], r.v[i + 1], r.v[i + 2], r.v[i + 3]);
+        for (int i = 0; i < VPL; i += 4) {
+            if constexpr (MODE == kPlain) {
+                *reinterpret_cast<float4*>(p + i * 64) = make_float4(r.v[i], r.v[i + 1], r.v[i + 2], r.v[i + 3]);
+            } else {
+                st2<MODE>(p + i * 64, r.v[i], r.v[i + 1]);
+                st2<MODE>(p + i * 64 + 2, r.v[i + 2], r.v[i + 3]);
+            }
+        }
     }
 }
 
+// row += delta, one float atomic per element, at the memory side
+template <int VPL>
+__device__ __forceinline__ void add_row(float* base, int64_t row, int stride, int lane, const Row<VPL>& d) {
+    float* q = base + row * stride + lane;  // same lane layout as load_row<VPL, kAtomic>
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+        __hip_atomic_fetch_add(q + i * 64, d.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // G = target slots in use per group of 8 (6 when negative == 5: the centre + 5 draws)
-template <int VPL, int G>
+template <int VPL, int G, int MODE>
 __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
     extern __shared__ int32_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -200,11 +266,14 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
             const int rb = (int)(hash32(a.seed, wid, (uint32_t)i, 0xB17) % (uint32_t)a.window);
             const int lo = max(0, i - a.window + rb), hi = min(n_eff, i + a.window + 1 - rb);
             if (hi - lo <= 1) continue;
-            Row<VPL> c = load_row<VPL>(a.syn1neg, ci, a.row_stride, lane);
+            Row<VPL> c = load_row<VPL, MODE>(a.syn1neg, ci, a.row_stride, lane);
+            Row<VPL> cd;  // kAtomic: this wave's accumulated change of the centre row
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) cd.v[v] = 0.f;
             for (int j = lo; j < hi; ++j) {
                 if (j == i) continue;
                 const int32_t xj = __builtin_amdgcn_readfirstlane(sent[j]);
-                Row<VPL> h = load_row<VPL>(a.syn0, xj, a.row_stride, lane);
+                Row<VPL> h = load_row<VPL, MODE>(a.syn0, xj, a.row_stride, lane);
                 Row<VPL> work;
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) work.v[v] = 0.f;
@@ -235,7 +304,7 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
                         if (k == 0 && t0 == 0) {
                             n[k] = c;
                         } else if (tgt[k] >= 0) {
-                            n[k] = load_row<VPL>(a.syn1neg, tgt[k], a.row_stride, lane);
+                            n[k] = load_row<VPL, MODE>(a.syn1neg, tgt[k], a.row_stride, lane);
                         } else {
 #pragma unroll
                             for (int v = 0; v < VPL; ++v) n[k].v[v] = 0.f;
@@ -264,24 +333,38 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
                         const float gk = __builtin_bit_cast(
                             float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), bitrev3(k)));
                         if (gk == 0.f) continue;  // |f| >= MAX_EXP: no update at all
+                        Row<VPL> dn;
 #pragma unroll
                         for (int v = 0; v < VPL; ++v) {
                             work.v[v] = fmaf(gk, n[k].v[v], work.v[v]);
-                            n[k].v[v] = fmaf(gk, h.v[v], n[k].v[v]);
+                            dn.v[v] = gk * h.v[v];
+                            n[k].v[v] += dn.v[v];
                         }
-                        if (k == 0 && t0 == 0) c = n[k];
-                        else store_row<VPL>(a.syn1neg, tgt[k], a.row_stride, lane, n[k]);
+                        if (k == 0 && t0 == 0) {
+                            c = n[k];
+#pragma unroll
+                            for (int v = 0; v < VPL; ++v) cd.v[v] += dn.v[v];
+                        } else if constexpr (MODE == kAtomic) {
+                            add_row<VPL>(a.syn1neg, tgt[k], a.row_stride, lane, dn);
+                        } else {
+                            store_row<VPL, MODE>(a.syn1neg, tgt[k], a.row_stride, lane, n[k]);
+                        }
                     }
                     // advance the walk's LCG past this group's negatives
                     const int used = min(a.negative, t0 + 7) - max(t0, 1) + 1;
                     for (int d = 0; d < used; ++d) lcg = (lcg * kLcgA + kLcgC) & kLcgMask;
                 }
+                if constexpr (MODE == kAtomic) {
+                    add_row<VPL>(a.syn0, xj, a.row_stride, lane, work);
+                } else {
 #pragma unroll
-                for (int v = 0; v < VPL; ++v) h.v[v] += work.v[v];
-                store_row<VPL>(a.syn0, xj, a.row_stride, lane, h);
+                    for (int v = 0; v < VPL; ++v) h.v[v] += work.v[v];
+                    store_row<VPL, MODE>(a.syn0, xj, a.row_stride, lane, h);
+                }
                 ++pairs_done;
             }
-            store_row<VPL>(a.syn1neg, ci, a.row_stride, lane, c);
+            if constexpr (MODE == kAtomic) add_row<VPL>(a.syn1neg, ci, a.row_stride, lane, cd);
+            else store_row<VPL, MODE>(a.syn1neg, ci, a.row_stride, lane, c);
         }
         __builtin_amdgcn_wave_barrier();  // LDS sentence is reused by the next walk
     }
@@ -378,7 +461,7 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
                               float min_alpha, int64_t sentences_base, int64_t sentences_step,
                               int64_t sentences_total, int64_t alpha_batch,
                               uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
-                              int32_t max_blocks, void* stream) {
+                              int32_t update_mode, int32_t max_blocks, void* stream) {
     if (n_walks < 0 || walk_stride < 1 || n_words < 1 || dim < 1 || window < 1 || negative < 0 || negative > 64)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad size (walks %lld x %d, words %lld, dim %d, window %d, negative %d)",
                          (long long)n_walks, (int)walk_stride, (long long)n_words, (int)dim, (int)window, (int)negative);
@@ -389,6 +472,8 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: row_stride %d must be a multiple of 64 in [dim, 512]",
                          (int)row_stride);
     if (lut_bits < 1 || lut_bits > 24) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: lut_bits %d", (int)lut_bits);
+    if (update_mode < kPlain || update_mode > kAtomic)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: update_mode %d", (int)update_mode);
     if (sentences_total < 1 || alpha_batch < 1 || sentences_step < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad schedule");
     hipStream_t st = (hipStream_t)stream;
     fill_exp_table();
@@ -409,12 +494,20 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     const size_t shmem = (size_t)4 * a.lpad * sizeof(int32_t);
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks + 3) / 4;
-    const int64_t cap = max_blocks > 0 ? max_blocks : 2048;  // 256 CUs x 8 blocks of 4 waves
+    // default grid: 256 CUs x 8 workgroups of 4 waves, but never more than one wave per two
+    // vocabulary rows — beyond that the racing waves read each other's rows so stale that
+    // small graphs train measurably differently from the sequential algorithm
+    int64_t cap = max_blocks > 0 ? max_blocks : 2048;
+    if (max_blocks <= 0 && cap > n_words / 8) cap = n_words / 8 > 0 ? n_words / 8 : 1;
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);
-#define N2V_SGNS_LAUNCH(V)                                                              \
-    if (negative <= 5) hipLaunchKernelGGL((sgns_kernel<V, 6>), grid, block, shmem, st, a); \
-    else hipLaunchKernelGGL((sgns_kernel<V, 8>), grid, block, shmem, st, a)
+#define N2V_SGNS_LAUNCH_M(V, M)                                                            \
+    if (negative <= 5) hipLaunchKernelGGL((sgns_kernel<V, 6, M>), grid, block, shmem, st, a); \
+    else hipLaunchKernelGGL((sgns_kernel<V, 8, M>), grid, block, shmem, st, a)
+#define N2V_SGNS_LAUNCH(V)                                   \
+    if (update_mode == kPlain) { N2V_SGNS_LAUNCH_M(V, kPlain); }        \
+    else if (update_mode == kAgent) { N2V_SGNS_LAUNCH_M(V, kAgent); }   \
+    else { N2V_SGNS_LAUNCH_M(V, kAtomic); }
     switch (row_stride / 64) {
         case 1: N2V_SGNS_LAUNCH(1); break;
         case 2: N2V_SGNS_LAUNCH(2); break;

@@ -18,6 +18,7 @@ import torch
 
 from . import _lib
 
+UPDATE_MODES = {"plain": 0, "agent": 1, "atomic": 2}  # N2V_SGNS_* of include/n2v_hip.h
 MAX_WORDS_IN_BATCH = 10000  # gensim: words per job; alpha is stepped once per job
 LUT_BITS = 20
 
@@ -64,7 +65,7 @@ class SgnsModel:
     """Embedding tables + vocabulary statistics of one training run, on one device."""
 
     def __init__(self, n_words, dim=128, window=10, negative=5, alpha=0.025, min_alpha=1e-4, sample=1e-3,
-                 seed=1, device=None):
+                 seed=1, device=None, update_mode="atomic"):
         if not torch.cuda.is_available():
             raise RuntimeError("n2v_hip: no GPU visible; the SGNS trainer has no CPU fallback")
         self.lib = _lib.load()
@@ -73,6 +74,7 @@ class SgnsModel:
         self.stride = _row_stride(self.dim)
         self.window, self.negative = int(window), int(negative)
         self.alpha, self.min_alpha, self.sample, self.seed = float(alpha), float(min_alpha), sample, int(seed)
+        self.update_mode = UPDATE_MODES[update_mode]
         d = self.device
         self.syn0 = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
         self.syn1neg = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
@@ -122,7 +124,7 @@ class SgnsModel:
                 _lib.ptr(self.cum_table), _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha,
                 int(sentences_base), int(sentences_step), int(sentences_total), alpha_batch,
                 self.seed & (2**64 - 1),
-                int(walk_id_base), _lib.ptr(self.pair_count), int(max_blocks), self._stream()))
+                int(walk_id_base), _lib.ptr(self.pair_count), self.update_mode, int(max_blocks), self._stream()))
 
     def pairs_trained(self):
         return int(self.pair_count.item())

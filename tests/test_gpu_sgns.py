@@ -76,8 +76,8 @@ def test_single_pair_update_matches_numpy(torch_cuda):
     torch = torch_cuda
     from n2v_hip import sgns
     d = torch.device("cuda:0")
-    for dim in (128, 64, 100, 256, 512):
-        m = sgns.SgnsModel(5, dim=dim, window=1, negative=0, sample=0, seed=3)
+    for dim, mode in [(d_, m_) for d_ in (128, 64, 100, 256, 512) for m_ in ("atomic", "agent", "plain")]:
+        m = sgns.SgnsModel(5, dim=dim, window=1, negative=0, sample=0, seed=3, update_mode=mode)
         # non-zero syn1neg so that both tables move
         m.syn1neg[:, :dim] = (torch.rand((5, dim), device=d) - 0.5) * 0.2
         walks = torch.tensor([[1, 3]], dtype=torch.int32, device=d)

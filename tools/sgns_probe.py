@@ -1,4 +1,7 @@
-"""Scratch probe (not a test): SGNS throughput on walks of a BASELINE config."""
+"""Scratch probe (not a test): SGNS throughput on walks of a BASELINE config, per sharing mode.
+
+    MODES=plain,agent,atomic python tools/sgns_probe.py C3 [rounds] [dim]
+"""
 import os
 import sys
 import time
@@ -22,22 +25,22 @@ def main():
     corpus = g.simulate_walks(rounds, 80)
     torch.cuda.synchronize()
     print(name, "walks", tuple(corpus.walks.shape), flush=True)
-    m = sgns.SgnsModel(cg.n_nodes, dim=dim, window=10, negative=5, seed=1)
-    t = time.perf_counter()
-    m.build_vocab(corpus.walks)
-    torch.cuda.synchronize()
-    print("build_vocab %.3fs" % (time.perf_counter() - t), flush=True)
-    for rep in range(3):
-        m.pair_count.zero_()
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        sgns.train(m, corpus.walks, corpus.lens, epochs=1)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t
-        n = m.pairs_trained()
-        print("pass %d: %.3fs  %d pairs  %.3e pairs/s  algorithmic %.2f TB/s" % (
-            rep, dt, n, n / dt, n / dt * 7168 * (m.stride / 128) / 1e12), flush=True)
-    print("finite:", bool(torch.isfinite(m.syn0).all()), "syn0 absmax %.3f" % float(m.syn0.abs().max()))
+    for mode in os.environ.get("MODES", "plain,agent,atomic").split(","):
+        m = sgns.SgnsModel(cg.n_nodes, dim=dim, window=10, negative=5, seed=1, update_mode=mode)
+        m.build_vocab(corpus.walks)
+        for rep in range(2):
+            m.pair_count.zero_()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            sgns.train(m, corpus.walks, corpus.lens, epochs=1)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            n = m.pairs_trained()
+            print("%-7s pass %d: %.3fs  %d pairs  %.3e pairs/s  algorithmic %.2f TB/s" % (
+                mode, rep, dt, n, n / dt, n / dt * 7168 * (m.stride / 128) / 1e12), flush=True)
+        print(mode, "finite:", bool(torch.isfinite(m.syn0).all()), "syn0 absmax %.3f" % float(m.syn0.abs().max()),
+              flush=True)
+        del m
 
 
 if __name__ == "__main__":
