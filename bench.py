@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--rounds", type=int, default=10, help="walks per start vertex per step and per GPU (BASELINE: 10)")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--syncs", type=int, default=16, help="replica merges per SGNS pass when N > 1")
+    ap.add_argument("--syncs", default="auto", help="replica merges per SGNS pass when N > 1 (auto: staleness bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     args = ap.parse_args()
@@ -189,10 +189,11 @@ def main():
     model = sgns.SgnsModel(N, dim=args.dim, window=window, negative=negative, seed=1, device=dev)
     model.build_vocab(counts=counts)
     shard_offset = pos_begin * rounds_total
+    syncs = (sgns.auto_syncs(n_global * L, N, world) if args.syncs == "auto" else int(args.syncs))
 
     def sgns_step(step_no):
         sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
-                   syncs_per_epoch=args.syncs)
+                   syncs_per_epoch=syncs)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     for s in range(args.warmup):
@@ -266,7 +267,7 @@ def main():
         "config": {"workload": desc, "walk_length": L, "rounds_per_gpu_per_step": args.rounds,
                    "walks_per_step_global": n_global, "window": window, "negative": negative, "dim": args.dim,
                    "rng": "philox4x32-10 in-kernel (walk rule bit-identical to the reference under given uniforms)",
-                   "sharding": "start-vertex shards, %d replica merges (RCCL all-reduce) per SGNS pass" % args.syncs
+                   "sharding": "start-vertex shards, %d delta merges (RCCL all-reduce of both tables) per SGNS pass" % syncs
                    if world > 1 else "single GPU", **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
                  "pairs_per_step_global": pairs_all / K, "seconds_per_step": t_sgns / K},

@@ -155,48 +155,114 @@ def shard_bounds(n_items, world, rank):
     return b, min(b + per, n_items)
 
 
-def merge_replicas(tables, bases, comm, mode):
+def merge_replicas(tables, bases, comm, mode="delta"):
     """Combine the replicas' tables in place at a sync point.
-    mode 'avg'   : mean of the replicas.
-    mode 'delta' : base + sum of every replica's change since the last sync (what a shared
-                   Hogwild table would have received); `bases` holds the last merged copy."""
+    mode 'delta' (default): base + sum of every replica's change since the last sync — what one
+                 shared Hogwild table would have received; `bases` holds the last merged copy.
+                 Faithful to the sequential algorithm as long as the interval between syncs is
+                 short (see auto_syncs); with long intervals the summed changes overshoot.
+    mode 'avg' : mean of the replicas (local SGD); `bases` entries may be None."""
     for t, b in zip(tables, bases):
         comm.all_reduce_sum(t)
         if mode == "avg":
             t.div_(comm.world)
-        else:
+        elif mode == "delta":
             t.sub_(b, alpha=comm.world - 1)
+        else:
+            raise ValueError("merge mode %r" % (mode,))
         if b is not None:
             b.copy_(t)
 
 
-def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch=16,
+# Staleness bound of the 'delta' merge, measured on one MI355X by training G simulated replicas
+# (tools/replica_auc_probe.py, 3000-node graph, CPU comparator AUC 0.8961): with
+# (G-1) * tokens per vocabulary row per interval at about 22 (G=8, 256 syncs) or 12 (G=2, 64
+# syncs) the AUC stays within 0.0005 of the sequential result; at 50 (G=2, 16 syncs) it is off
+# by 0.0023 and at 87 (G=8, 64 syncs) training diverges.
+STALENESS_BUDGET = 20.0
+
+
+def auto_syncs(tokens_global, n_words, world):
+    """Merges per pass so that (world-1) * tokens per row per interval <= STALENESS_BUDGET."""
+    if world <= 1:
+        return 1
+    return max(1, int(np.ceil(tokens_global * (world - 1) / (STALENESS_BUDGET * max(n_words, 1)))))
+
+
+def chunk_plan(n_local, n_chunks):
+    """[begin, end) of every merge interval of a pass over n_local sentences."""
+    n_chunks = max(1, min(int(n_chunks), max(n_local, 1)))
+    return [shard_bounds(n_local, n_chunks, c) for c in range(n_chunks)]
+
+
+def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
           merge="delta"):
-    """Train `epochs` passes over this rank's walks.  With a communicator, replicas are merged
-    `syncs_per_epoch` times per epoch (the last one at the epoch boundary)."""
+    """Train `epochs` passes over this rank's walks.  With a communicator the replicas are
+    merged `syncs_per_epoch` times per pass ("auto": auto_syncs), the last one at its end."""
     n_local = int(walks.shape[0])
     if n_walks_global is None:
         n_walks_global = n_local
     total = epochs * n_walks_global
     world = comm.world if comm is not None else 1
     bases = None
+    n_chunks = 1
     if world > 1:
         bases = [model.syn0.clone(), model.syn1neg.clone()] if merge == "delta" else [None, None]
-        n_chunks = max(1, int(syncs_per_epoch))
-    else:
-        n_chunks = 1
+        n_chunks = (auto_syncs(n_walks_global * int(walks.shape[1]), model.n_words, world)
+                    if syncs_per_epoch == "auto" else int(syncs_per_epoch))
+    plan = chunk_plan(n_local, n_chunks)
     for ep in range(epochs):
-        for c in range(n_chunks):
-            b, e = shard_bounds(n_local, n_chunks, c)
+        for b, e in plan:
             if e > b:
                 # all replicas advance together: `b` local sentences = b * world global ones
                 model.train_pass(walks[b:e], None if lens is None else lens[b:e],
                                  sentences_base=ep * n_walks_global + b * world, sentences_step=world,
-                                 sentences_total=total,
-                                 walk_id_base=ep * n_walks_global + shard_offset + b)
+                                 sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b)
             if world > 1:
                 merge_replicas([model.syn0, model.syn1neg], bases, comm, merge)
     return model
+
+
+class _SimulatedComm:
+    """all_reduce_sum over replicas that live in ONE process (validation only: the replicas'
+    merges are executed one after another on snapshots taken before any of them is changed)."""
+
+    def __init__(self, world, snapshots):
+        self.world, self._snap, self._i = world, snapshots, 0
+
+    def all_reduce_sum(self, t):
+        total = self._snap[self._i][0].clone()
+        for x in self._snap[self._i][1:]:
+            total += x
+        t.copy_(total)
+        self._i += 1
+
+
+def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="delta", epochs=1):
+    """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens,
+    shard_offset)` what rank r would hold.  Runs the same schedule and the same merge_replicas
+    arithmetic as `train`, interval by interval, so the multi-GPU scheme can be scored for AUC
+    on a one-GPU box."""
+    G = len(models)
+    L = int(shards[0][0].shape[1])
+    n_chunks = (auto_syncs(n_walks_global * L, models[0].n_words, G) if syncs_per_epoch == "auto"
+                else int(syncs_per_epoch))
+    bases = [[m.syn0.clone(), m.syn1neg.clone()] if merge == "delta" else [None, None] for m in models]
+    plans = [chunk_plan(int(w.shape[0]), n_chunks) for w, _, _ in shards]
+    total = epochs * n_walks_global
+    for ep in range(epochs):
+        for c in range(len(plans[0])):
+            for r, m in enumerate(models):
+                w, l, off = shards[r]
+                b, e = plans[r][c] if c < len(plans[r]) else (0, 0)
+                if e > b:
+                    m.train_pass(w[b:e], None if l is None else l[b:e], sentences_base=ep * n_walks_global + b * G,
+                                 sentences_step=G, sentences_total=total,
+                                 walk_id_base=ep * n_walks_global + off + b)
+            snaps = [[m.syn0.clone() for m in models], [m.syn1neg.clone() for m in models]]
+            for r, m in enumerate(models):
+                merge_replicas([m.syn0, m.syn1neg], bases[r], _SimulatedComm(G, snaps), merge)
+    return n_chunks
 
 
 # --------------------------------------------------------------------------- gensim-like results

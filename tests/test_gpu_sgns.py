@@ -225,3 +225,44 @@ def test_learn_embeddings_dropin_surface(torch_cuda, tmp_path):
     n2v_main.args = args
     model2 = n2v_main.learn_embeddings([[1, 2, 3, 4], [4, 3, 2, 1, 34]])
     assert set(model2.wv.vocab) == {"1", "2", "3", "4", "34"}
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, G):
+    """The multi-GPU scheme (start-vertex shards, one replica per rank, 'delta' merges at the
+    auto_syncs cadence) scored on ONE GPU by training G replicas interval by interval with the
+    same schedule and merge arithmetic as n2v_hip.sgns.train: AUC within +-0.002 of the
+    sequential CPU comparator (0.89607 for this graph and these walks, see the test above)."""
+    torch = torch_cuda
+    import node2vec
+    from n2v_hip import linkpred, sgns
+    from oracle import c_oracle, sgns_oracle
+    g, te, neg = _auc_setup()
+    Gr = node2vec.Graph.from_csr(g, 1.0, 1.0, rng="philox", seed=1)
+    Gr.preprocess_transition_probs()
+    rounds = 10
+    corpus = Gr.simulate_walks(rounds, 80)
+    n = g.n_nodes
+    counts = torch.bincount(corpus.walks.reshape(-1).long(), minlength=n)
+    models, shards = [], []
+    for r in range(G):
+        m = sgns.SgnsModel(n, dim=128, window=10, negative=5, seed=1)
+        m.build_vocab(counts=counts)
+        models.append(m)
+        b, e = sgns.shard_bounds(n, G, r)
+        idx = (torch.arange(rounds, device="cuda")[:, None] * n + torch.arange(b, e, device="cuda")[None, :]).reshape(-1)
+        shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
+    n_syncs = sgns.train_simulated_replicas(models, shards, n_walks_global=corpus.walks.shape[0])
+    torch.cuda.synchronize()
+    for m in models[1:]:
+        assert torch.equal(m.syn0, models[0].syn0) and torch.equal(m.syn1neg, models[0].syn1neg)
+    te_d = np.stack([g.dense_of(te[:, 0]), g.dense_of(te[:, 1])], 1)
+    neg_d = np.stack([g.dense_of(neg[:, 0]), g.dense_of(neg[:, 1])], 1)
+    auc, _ = linkpred.get_roc_score(models[0].vectors(), te_d, neg_d)
+    si, cum = sgns_oracle.vocab_tables(counts.cpu().numpy(), 1e-3)
+    syn0, syn1 = c_oracle.sgns_init(n, 128, 128, 1)
+    c_oracle.sgns_train(corpus.walks.cpu().numpy(), corpus.lens.cpu().numpy(), syn0, syn1, 128, 10, 5, si, cum,
+                        n_threads=1)
+    auc_cpu, _ = linkpred.get_roc_score(torch.from_numpy(syn0).cuda(), te_d, neg_d)
+    print("G=%d syncs=%d: AUC %.5f vs sequential CPU %.5f" % (G, n_syncs, auc, auc_cpu))
+    assert abs(auc - auc_cpu) <= AUC_BAND, (G, n_syncs, auc, auc_cpu)

@@ -39,6 +39,29 @@ def test_shard_bounds_cover_exactly():
             assert all(e >= b for b, e in got)
 
 
+def test_auto_syncs_and_chunk_plan():
+    from n2v_hip.sgns import STALENESS_BUDGET, auto_syncs, chunk_plan
+    assert auto_syncs(10**9, 10**6, 1) == 1
+    for world in (2, 8):
+        k = auto_syncs(30000 * 80, 3000, world)
+        assert (world - 1) * (30000 * 80 / k) / 3000 <= STALENESS_BUDGET
+        assert (world - 1) * (30000 * 80 / max(k - 1, 1)) / 3000 > STALENESS_BUDGET or k == 1
+    plan = chunk_plan(1001, 16)
+    assert plan[0][0] == 0 and plan[-1][1] == 1001 and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+    assert len(chunk_plan(5, 100)) == 5 and chunk_plan(0, 4) == [(0, 0)]
+
+
+def test_simulated_comm_equals_sum():
+    from n2v_hip.sgns import _SimulatedComm, merge_replicas
+    base = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    reps = [base + 1.0, base + 10.0, base + 100.0]
+    snaps = [[r.clone() for r in reps]]
+    for r in reps:
+        b = [base.clone()]
+        merge_replicas([r], b, _SimulatedComm(3, snaps), "delta")
+        assert torch.equal(r, base + 111.0) and torch.equal(b[0], r)
+
+
 def test_linkpred_metrics_match_sklearn():
     from sklearn.metrics import average_precision_score, roc_auc_score
     from n2v_hip import linkpred
@@ -74,14 +97,14 @@ for mode in ("avg", "delta"):
     bases = [base0.clone()]
     t[rank] += 1.0 + rank            # each replica changes its own row ...
     t[2] += 10.0 * (rank + 1)        # ... and both change row 2
-    sgns.merge_replicas([t], bases if mode == "delta" else [None], comm, mode)
+    sgns.merge_replicas([t], bases if mode != "avg" else [None], comm, mode)
     want = base0.clone()
     if mode == "avg":
         want[0] += 0.5; want[1] += 1.0; want[2] += 15.0
     else:
         want[0] += 1.0; want[1] += 2.0; want[2] += 30.0
     assert torch.allclose(t, want), (mode, t, want)
-    if mode == "delta":
+    if mode != "avg":
         assert torch.equal(bases[0], t)
 b, e = sgns.shard_bounds(101, 2, rank)
 tot = torch.tensor([e - b]); dist.all_reduce(tot); assert int(tot) == 101

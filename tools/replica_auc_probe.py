@@ -1,0 +1,104 @@
+"""Scratch probe: link-prediction AUC when G replicas train on start-vertex shards and are
+merged (delta / avg) `syncs` times per pass — the multi-GPU scheme of n2v_hip/sgns.py:train —
+simulated on ONE GPU by training the replicas' chunks one after another."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "node2vec-by-ecc_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import node2vec
+from n2v_hip import linkpred, sgns
+from test_gpu_sgns import _auc_setup
+
+
+def simulate(G, corpus, n_nodes, rounds, merge, syncs, mode="atomic"):
+    n = corpus.walks.shape[0] // rounds
+    models = [sgns.SgnsModel(n_nodes, dim=128, window=10, negative=5, seed=1, update_mode=mode) for _ in range(G)]
+    counts = torch.bincount(corpus.walks.reshape(-1).long(), minlength=n_nodes)
+    for m in models:
+        m.build_vocab(counts=counts)
+    shards = []
+    for r in range(G):
+        b, e = sgns.shard_bounds(n, G, r)
+        idx = (torch.arange(rounds, device=corpus.walks.device)[:, None] * n +
+               torch.arange(b, e, device=corpus.walks.device)[None, :]).reshape(-1)
+        shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
+    n_global = corpus.walks.shape[0]
+    bases = [models[0].syn0.clone(), models[0].syn1neg.clone()]
+    for c in range(syncs):
+        for r, m in enumerate(models):
+            w, l, off = shards[r]
+            b, e = sgns.shard_bounds(w.shape[0], syncs, c)
+            if e > b:
+                m.train_pass(w[b:e], l[b:e], sentences_base=b * G, sentences_step=G, sentences_total=n_global,
+                             walk_id_base=off + b)
+        for ti, name in enumerate(("syn0", "syn1neg")):
+            stack = torch.stack([getattr(m, name) for m in models])
+            if merge == "avg":
+                new = stack.mean(0)
+            elif merge == "delta":
+                new = bases[ti] + (stack - bases[ti][None]).sum(0)
+            else:  # sparse_avg, as n2v_hip.sgns.merge_replicas
+                delta = stack - bases[ti][None]
+                cnt = (delta != 0).any(dim=2).float().sum(0).clamp_min(1.0)
+                new = bases[ti] + delta.sum(0) / cnt[:, None]
+            for m in models:
+                getattr(m, name).copy_(new)
+            bases[ti].copy_(new)
+    return models[0]
+
+
+def setup(kind):
+    if kind == "pp":
+        return _auc_setup()
+    from n2v_hip import csr, synth
+    from oracle import sgns_oracle
+    n = int(kind.split(":")[1]) if ":" in kind else 20000
+    u, v = synth.barabasi_albert_edges(n, 10, 42)
+    edges = np.stack([u, v], 1)
+    tr, te = sgns_oracle.split_edges(edges)
+    g = csr.from_edges(tr[:, 0], tr[:, 1], None, False)
+    ing = set(g.labels.tolist())
+    te = np.array([e for e in te.tolist() if e[0] in ing and e[1] in ing])
+    neg = np.array(sgns_oracle.build_neg_samples(g.labels.tolist(), edges.tolist(), seed=0))
+    return g, te, neg
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "pp"
+    g, te, neg = setup(kind)
+    Gr = node2vec.Graph.from_csr(g, 1.0, 1.0, rng="philox", seed=1)
+    Gr.preprocess_transition_probs()
+    rounds = 10
+    corpus = Gr.simulate_walks(rounds, 80)
+    te_d = np.stack([g.dense_of(te[:, 0]), g.dense_of(te[:, 1])], 1)
+    neg_d = np.stack([g.dense_of(neg[:, 0]), g.dense_of(neg[:, 1])], 1)
+    from oracle import c_oracle, sgns_oracle
+    import time
+    counts = np.bincount(corpus.walks.cpu().numpy().reshape(-1), minlength=g.n_nodes)
+    si, cum = sgns.vocab_tables(counts, 1e-3)
+    for thr in ((1, 64) if kind == "pp" else (64,)):
+        syn0, syn1 = c_oracle.sgns_init(g.n_nodes, 128, 128, 1)
+        t = time.time()
+        c_oracle.sgns_train(corpus.walks.cpu().numpy(), corpus.lens.cpu().numpy(), syn0, syn1, 128, 10, 5, si, cum,
+                            n_threads=thr)
+        auc, ap = linkpred.get_roc_score(torch.from_numpy(syn0).cuda(), te_d, neg_d)
+        print("CPU comparator threads=%d: AUC %.5f AP %.5f (%.0fs)" % (thr, auc, ap, time.time() - t), flush=True)
+    m = simulate(1, corpus, g.n_nodes, rounds, "avg", 1)
+    print("G=1: AUC %.5f" % linkpred.get_roc_score(m.vectors(), te_d, neg_d)[0], flush=True)
+    sync_list = [int(x) for x in os.environ.get("SYNCS", "4,16,64").split(",")]
+    for G in (2, 8):
+        for merge in os.environ.get("MERGES", "sparse_avg,avg,delta").split(","):
+            for syncs in sync_list:
+                m = simulate(G, corpus, g.n_nodes, rounds, merge, syncs)
+                auc, ap = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
+                print("G=%d merge=%-10s syncs=%3d: AUC %.5f AP %.5f" % (G, merge, syncs, auc, ap), flush=True)
+
+
+if __name__ == "__main__":
+    main()
