@@ -115,6 +115,22 @@ int n2v_walk(const int64_t* row_ptr, const n2v_alias_slot* node_slots, const n2v
              int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
              int32_t* walks, int32_t* lens, void* stream);
 
+/* simulate_walks_on_the_fly / node2vec_walk_on_the_fly (src/node2vec.py:13-53,97-111): the
+ * same walk with the (prev, cur) table rebuilt at every step instead of read from the edge
+ * tables (for graphs whose sum of deg^2 slots does not fit in HBM).  Output is identical to
+ * n2v_walk under the same uniforms.  One wavefront per walk; tables of up to 512 slots are
+ * built in LDS, larger ones in `scratch` (n2v_alias_slot[scratch_slots]; the launch uses
+ * floor(scratch_slots / max_degree) wavefronts, at least 4 are required when
+ * max_degree > 512; may be NULL otherwise).  status: int32[1], N2V_STATUS_ZERO_NORM on a
+ * zero-sum neighbourhood.  Other arguments as n2v_walk.                                   */
+int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
+                        int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+                        int64_t pos_count, int64_t round_begin, int64_t round_count,
+                        int32_t walk_length, int32_t rng_mode, const double* uniforms,
+                        const int64_t* walk_uoff, uint64_t seed, n2v_alias_slot* scratch,
+                        int64_t scratch_slots, int32_t* walks, int32_t* lens, int32_t* status,
+                        void* stream);
+
 /* ---- learn_embeddings (src/main.py:82-90 -> gensim 3.2.0 Word2Vec, sg=1, negative sampling) --
  * gensim is a third-party dependency absent from the reference tree (requirements.txt:17);
  * these entry points restate its public algorithm.

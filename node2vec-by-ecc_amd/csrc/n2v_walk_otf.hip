@@ -1,0 +1,221 @@
+// On-the-fly 2nd-order walk — gfx950 (MI355X).
+//
+// Replaces Graph.node2vec_walk_on_the_fly / simulate_walks_on_the_fly of the reference
+// (src/node2vec.py:13-53,97-111): the alias table of (prev, cur) is rebuilt at every step
+// instead of being read from the Σdeg² tables of preprocess_transition_probs — the reference's
+// own answer to graphs whose edge tables do not fit in memory.  The result is identical to
+// the table-driven walk (same table bits, same two uniforms per step), so walks are
+// bit-identical to n2v_walk / the reference under the same uniforms.
+//
+// One wavefront owns one walk.  Per step the wave
+//   1. gathers cur's row (ids, weights) cooperatively and classifies every neighbour
+//      (== prev: w/p; has_edge(nbr, prev): w; else w/q — src/node2vec.py:142-148) in parallel,
+//   2. has ONE lane do the two inherently serial pieces exactly as the reference does — the
+//      left-to-right fp64 sum (:149) and Vose's stack pairing (:259-268),
+//   3. normalises (divide, then multiply by K) in parallel again, and draws.
+// The table lives in the wave's slice of LDS while K <= kLdsSlots and in a per-wave global
+// scratch row of max_degree slots otherwise.  Serial chains of many waves interleave on a
+// SIMD, so throughput comes from occupancy; -ffp-contract=off keeps every rounding separate.
+#include "n2v_common.h"
+
+namespace {
+
+constexpr int kLdsSlots = 512;  // 8 KiB of LDS per wave, 32 KiB per 4-wave workgroup
+
+struct OtfArgs {
+    const int64_t* row_ptr;
+    const int32_t* col;
+    const double* w;
+    double p, q;
+    const int32_t* starts;
+    int64_t n_starts, pos_begin, pos_count, round_begin, n_local;
+    int32_t L;
+    int32_t rng_mode;
+    const double* uniforms;
+    const int64_t* walk_uoff;
+    uint64_t seed;
+    n2v_alias_slot* scratch;  // [n_waves][max_degree]
+    int64_t max_degree;
+    int32_t* walks;
+    int32_t* lens;
+    int32_t* status;
+};
+
+__device__ __forceinline__ void philox_uniforms(uint64_t seed, uint64_t walk, uint32_t step, double& u1, double& u2) {
+    uint32_t c0 = (uint32_t)walk, c1 = (uint32_t)(walk >> 32), c2 = step, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u1 = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
+    u2 = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) / 9007199254740992.0;
+}
+
+__device__ __forceinline__ bool row_contains(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                             int32_t u, int32_t v) {
+    int64_t lo = row_ptr[u];
+    const int64_t end = row_ptr[u + 1];
+    int64_t hi = end;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (col[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < end && col[lo] == v;
+}
+
+// serial pieces, run by one lane: T[k].q holds the unnormalised weights on entry of sum_serial,
+// the probabilities times K on entry of pair_serial
+template <typename SlotPtr>
+__device__ __forceinline__ double sum_serial(SlotPtr T, int K) {
+    double norm = 0.0;
+    for (int k = 0; k < K; ++k) norm = norm + T[k].q;  // sum(), src/node2vec.py:149/:22
+    return norm;
+}
+
+template <typename SlotPtr>
+__device__ __forceinline__ void pair_serial(SlotPtr T, int K) {
+    int ns = 0, nl = 0;
+    for (int k = 0; k < K; ++k) {  // :252-257 (q[kk] = K*prob already applied by the wave)
+        if (T[k].q < 1.0) T[ns++].aux = k;
+        else T[K - (++nl)].aux = k;
+    }
+    while (ns > 0 && nl > 0) {  // :259-268
+        const int small = T[--ns].aux;
+        const int large = T[K - nl].aux;
+        --nl;
+        T[small].J = large;
+        double t = T[large].q + T[small].q;
+        t = t - 1.0;
+        T[large].q = t;
+        if (t < 1.0) T[ns++].aux = large;
+        else T[K - (++nl)].aux = large;
+    }
+}
+
+// one step's table for (prev -> cur); prev < 0 means the first step (node table, :13-25)
+template <typename SlotPtr>
+__device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t prev, int64_t base, int K, int lane) {
+    for (int k = lane; k < K; k += 64) {
+        const int32_t nb = a.col[base + k];
+        const double wt = a.w ? a.w[base + k] : 1.0;
+        double u;
+        if (prev < 0) u = wt;
+        else if (nb == prev) u = wt / a.p;
+        else if (row_contains(a.row_ptr, a.col, nb, prev)) u = wt;
+        else u = wt / a.q;
+        T[k].q = u;
+        T[k].J = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double norm = 0.0;
+    if (lane == 0) norm = sum_serial(T, K);
+    norm = __shfl(norm, 0);
+    if (norm == 0.0) return false;  // ZeroDivisionError in the reference (:150/:23)
+    const double Kd = (double)K;
+    for (int k = lane; k < K; k += 64) {
+        const double prob = T[k].q / norm;  // :150
+        T[k].q = Kd * prob;                 // :253
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) pair_serial(T, K);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+
+__global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
+    __shared__ n2v_alias_slot lds[4 * kLdsSlots];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    n2v_alias_slot* Tl = lds + wv * kLdsSlots;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
+    n2v_alias_slot* Tg = a.scratch + wave_global * a.max_degree;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int32_t L = a.L;
+
+    for (int64_t lw = wave_global; lw < a.n_local; lw += n_waves) {
+        const int64_t rl = lw / a.pos_count, pl = lw - rl * a.pos_count;
+        const uint64_t gw = (uint64_t)((a.round_begin + rl) * a.n_starts + a.pos_begin + pl);
+        int32_t cur = a.starts[a.pos_begin + pl], prev = -1;
+        int32_t* out = a.walks + lw * (int64_t)L;
+        const double* up = nullptr;
+        if (a.rng_mode == N2V_RNG_UNIFORMS)
+            up = a.uniforms + (a.walk_uoff ? a.walk_uoff[lw] : (int64_t)2 * (L - 1) * lw);
+        if (lane == 0) out[0] = cur;
+        int32_t len = 1;
+        bool failed = false;
+        for (; len < L; ++len) {
+            const int64_t base = a.row_ptr[cur];
+            const int K = (int)(a.row_ptr[cur + 1] - base);
+            if (K == 0) break;  // dead end (:50-51)
+            bool ok;
+            if (K <= kLdsSlots) ok = build_table(a, Tl, prev, base, K, lane);
+            else ok = build_table(a, Tg, prev, base, K, lane);
+            if (!ok) { failed = true; break; }
+            double u1, u2;
+            const uint32_t t = (uint32_t)(len - 1);
+            if (a.rng_mode == N2V_RNG_UNIFORMS) { u1 = up[2 * (int64_t)t]; u2 = up[2 * (int64_t)t + 1]; }
+            else philox_uniforms(a.seed, gw, t, u1, u2);
+            const int kk = (int)(u1 * (double)K);  // :277
+            double qk; int Jk;
+            if (K <= kLdsSlots) { qk = Tl[kk].q; Jk = Tl[kk].J; }
+            else { qk = Tg[kk].q; Jk = Tg[kk].J; }
+            const int pick = (u2 < qk) ? kk : Jk;  // :278-281
+            prev = cur;
+            cur = a.col[base + pick];
+            if (lane == 0) out[len] = cur;
+            __builtin_amdgcn_wave_barrier();  // the table is rebuilt in place on the next step
+        }
+        if (failed && lane == 0) atomicOr(a.status, N2V_STATUS_ZERO_NORM);
+        if (lane == 0) {
+            a.lens[lw] = len;
+            for (int32_t i = len; i < L; ++i) out[i] = -1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
+                                   int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+                                   int64_t pos_count, int64_t round_begin, int64_t round_count, int32_t walk_length,
+                                   int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
+                                   n2v_alias_slot* scratch, int64_t scratch_slots, int32_t* walks, int32_t* lens,
+                                   int32_t* status, void* stream) {
+    if (pos_count < 0 || round_count < 0 || pos_begin < 0 || round_begin < 0 || walk_length < 1 ||
+        pos_begin + pos_count > n_starts || max_degree < 0)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: bad shard or length");
+    const int64_t n_local = pos_count * round_count;
+    if (n_local == 0) return N2V_OK;
+    if (!row_ptr || !col || !starts || !walks || !lens || !status)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: null pointer");
+    if (!(p == p) || !(q == q) || p == 0.0 || q == 0.0)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: p and q must be non-zero numbers");
+    if (rng_mode != N2V_RNG_UNIFORMS && rng_mode != N2V_RNG_PHILOX)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: rng_mode %d", (int)rng_mode);
+    if (rng_mode == N2V_RNG_UNIFORMS && walk_length > 1 && !uniforms)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: parity mode needs a uniform buffer");
+    // grid: as many resident waves as the scratch rows allow (5 workgroups of 4 waves per CU by LDS)
+    int64_t blocks = (n_local + 3) / 4;
+    if (blocks > 256 * 5) blocks = 256 * 5;
+    if (max_degree > kLdsSlots) {
+        if (!scratch) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: scratch needed (max degree %lld > %d)",
+                                       (long long)max_degree, kLdsSlots);
+        const int64_t fit = scratch_slots / max_degree / 4;
+        if (fit < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: scratch smaller than 4 x max_degree slots");
+        if (blocks > fit) blocks = fit;
+    }
+    OtfArgs a{row_ptr, col, w, p, q, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
+              rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, walks, lens, status};
+    hipLaunchKernelGGL(walk_otf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return n2v::check_launch("n2v_walk_on_the_fly");
+}

@@ -179,7 +179,7 @@ def merge_replicas(tables, bases, comm, mode="delta"):
 # (G-1) * tokens per vocabulary row per interval at about 22 (G=8, 256 syncs) or 12 (G=2, 64
 # syncs) the AUC stays within 0.0005 of the sequential result; at 50 (G=2, 16 syncs) it is off
 # by 0.0023 and at 87 (G=8, 64 syncs) training diverges.
-STALENESS_BUDGET = 20.0
+STALENESS_BUDGET = 12.0
 
 
 def auto_syncs(tokens_global, n_words, world):

@@ -244,7 +244,7 @@ class Graph():
         '''
         Repeatedly simulate random walks from each node.
         '''
-        if self._engine is None:
+        if self._engine is None or not self._engine.ready:
             raise AttributeError("'Graph' object has no attribute 'alias_nodes'")  # as the reference would
         if verbose:
             for walk_iter in range(num_walks):
@@ -252,28 +252,45 @@ class Graph():
         walks, lens = self._simulate(num_walks, walk_length, self._starts(nodes))
         return WalkCorpus(walks, lens, self._csr.labels)
 
-    # src/node2vec.py:97-111 — identical output to simulate_walks for popwalk == "none";
-    # the tables are built on first use instead of per step.
+    # src/node2vec.py:97-111 — identical output to simulate_walks for popwalk == "none".
+    # Needs no preprocess_transition_probs(): the (prev, cur) table is rebuilt at every step
+    # by the on-the-fly kernel (no sum-of-deg^2 storage).  If the tables already exist they
+    # are used instead (same walks, faster) unless `self.force_on_the_fly` is set.
     def simulate_walks_on_the_fly(self, num_walks, walk_length, nodes=None, verbose=False):
+        self._check_popwalk()
+        if verbose:
+            for walk_iter in range(num_walks):
+                print(str(walk_iter + 1), '/', str(num_walks))
+        otf = self._otf_engine()
+        walks, lens = self._simulate(num_walks, walk_length, self._starts(nodes), otf=otf)
+        return WalkCorpus(walks, lens, self._csr.labels)
+
+    def _otf_engine(self):
+        """True if the on-the-fly kernel has to (or is asked to) run; makes sure an engine
+        (graph on the device, no tables) exists."""
+        if self._engine is not None and self._engine.ready and not getattr(self, "force_on_the_fly", False):
+            return False
         if self._engine is None:
-            self.preprocess_transition_probs()
-        return self.simulate_walks(num_walks, walk_length, nodes=nodes, verbose=verbose)
+            self._engine = WalkEngine(self._csr, self.p, self.q, device=self.device)
+        return True
 
     # src/node2vec.py:55-79
     def node2vec_walk(self, walk_length, start_node):
-        if self._engine is None:
+        if self._engine is None or not self._engine.ready:
             raise AttributeError("'Graph' object has no attribute 'alias_nodes'")
         walks, lens = self._simulate(1, walk_length, self._csr.dense_of([start_node]))
         return WalkCorpus(walks, lens, self._csr.labels)[0]
 
     def node2vec_walk_on_the_fly(self, walk_length, start_node):
-        if self._engine is None:
-            self.preprocess_transition_probs()
-        return self.node2vec_walk(walk_length, start_node)
+        self._check_popwalk()
+        otf = self._otf_engine()
+        walks, lens = self._simulate(1, walk_length, self._csr.dense_of([start_node]), otf=otf)
+        return WalkCorpus(walks, lens, self._csr.labels)[0]
 
     # ------------------------------------------------------------------ internals
-    def _simulate(self, num_walks, walk_length, starts_host):
+    def _simulate(self, num_walks, walk_length, starts_host, otf=False):
         eng = self._engine
+        self._walk = eng.walk_on_the_fly if otf else eng.walk
         d = eng.device
         L = max(int(walk_length), 1)  # walk = [start] even for walk_length <= 1 (:63-65)
         num_walks = int(num_walks)
@@ -282,7 +299,7 @@ class Graph():
         if n * num_walks == 0:
             return (torch.empty((0, L), dtype=torch.int32, device=d), torch.empty(0, dtype=torch.int32, device=d))
         if self.rng == "philox":
-            return eng.walk(starts, num_walks, L, rng="philox", seed=self.seed)
+            return self._walk(starts, num_walks, L, rng="philox", seed=self.seed)
         if self.rng != "numpy":
             raise ValueError("rng must be 'numpy' or 'philox'")
         return self._simulate_numpy_stream(starts, n, num_walks, L)
@@ -299,7 +316,7 @@ class Graph():
         total_full = int(uoff[-1].item())
         uoff = torch.cat([torch.zeros(1, dtype=torch.int64, device=d), uoff[:-1]]).contiguous()
         if total_full == 0:
-            return eng.walk(starts, num_walks, L, rng="uniforms",
+            return self._walk(starts, num_walks, L, rng="uniforms",
                             uniforms=torch.zeros(2, dtype=torch.float64, device=d), walk_uoff=uoff)
         # a walk can end early only at a node without out-neighbours that is reachable,
         # i.e. never on an undirected graph (every visited node has the edge it came by)
@@ -317,13 +334,13 @@ class Graph():
                 k = min(rounds_per_chunk, num_walks - it)
                 U = torch.from_numpy(np.random.random_sample(per * k)).to(d)
                 off = uoff[:n * k].contiguous() if k > 1 else uoff_round
-                eng.walk(starts, k, L, rng="uniforms", uniforms=U, walk_uoff=off, round_begin=it,
+                self._walk(starts, k, L, rng="uniforms", uniforms=U, walk_uoff=off, round_begin=it,
                          out=(walks[it * n:(it + k) * n], lens[it * n:(it + k) * n]))
                 it += k
             return walks, lens
         state = np.random.get_state()
         U = torch.from_numpy(np.random.random_sample(total_full)).to(d)
-        walks, lens = eng.walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
+        walks, lens = self._walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
         # offsets depend on the lengths of all earlier walks: iterate to the fixed point
         # (each pass makes at least the first not-yet-final walk final)
         for _ in range(W + 1):
@@ -332,7 +349,7 @@ class Graph():
             if torch.equal(new_off, uoff):
                 break
             uoff = new_off
-            walks, lens = eng.walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
+            walks, lens = self._walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
         used = int(((lens.to(torch.int64) - 1) * 2).sum().item())
         np.random.set_state(state)
         if used:

@@ -221,3 +221,70 @@ def test_walk_lengths_not_multiple_of_4_and_length_1(n2v):
         got = g.simulate_walks(2, L)
         want = o.simulate_walks(2, L, seed=3)
         assert got == want, L
+
+
+@pytest.mark.parametrize("name", GRAPH_CASES)
+def test_on_the_fly_kernel_matches_reference(n2v, name):
+    """simulate_walks_on_the_fly WITHOUT preprocess_transition_probs (src/node2vec.py:97-111):
+    the per-step table rebuild kernel reproduces the reference's walks and stream position."""
+    z = load_case(name)
+    g = n2v.Graph(_nx_graph(z), bool(z["directed"]), float(z["p"]), float(z["q"]))
+    for i, (seed, r, L, ndraws, has_sub, fly) in enumerate(z["walk_meta"].tolist()):
+        sub = z["walks_%d_subset" % i].tolist() if has_sub else None
+        np.random.seed(seed)
+        walks = g.simulate_walks_on_the_fly(r, L, nodes=sub)
+        assert g._engine is not None and not g._engine.ready  # no tables were built
+        assert walks == golden_walks(z, i), (name, i)
+        chk = np.random.RandomState(seed)
+        chk.random_sample(ndraws)
+        assert np.random.random_sample() == chk.random_sample()
+    np.random.seed(5)
+    w1 = g.node2vec_walk_on_the_fly(9, z["nodes"].tolist()[0])
+    from oracle import n2v_oracle as orc
+    o = orc.Node2VecOracle(oracle_graph(z), bool(z["directed"]), float(z["p"]), float(z["q"]))
+    assert w1 == o.node2vec_walk(9, z["nodes"].tolist()[0], np.random.RandomState(5).random_sample, on_the_fly=True)
+
+
+@pytest.mark.parametrize("weighted,directed,p,q", [(False, False, 0.25, 4.0), (True, True, 0.5, 2.0)])
+def test_on_the_fly_kernel_equals_table_walk_with_hubs(n2v, weighted, directed, p, q):
+    """20k nodes plus hubs of degree 700 and 3000 (tables beyond the 512-slot LDS window go
+    through the global scratch path): on-the-fly walks == table-driven walks, bit for bit."""
+    import torch
+    rs = np.random.RandomState(11)
+    n, m = 20000, 80000
+    src = rs.randint(0, n, size=m)
+    dst = rs.randint(0, n, size=m)
+    hub_s = np.concatenate([np.full(700, 5), np.full(3000, 17)])
+    hub_d = np.concatenate([rs.choice(n, 700, replace=False), rs.choice(n, 3000, replace=False)])
+    src, dst = np.concatenate([src, hub_s, hub_d[:500]]), np.concatenate([dst, hub_d, hub_s[:500]])
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    w = (rs.random_sample(len(src)) * 3 + 0.25) if weighted else None
+    from n2v_hip import csr
+    cg = csr.from_edges(src, dst, w, directed)
+    assert cg.degrees.max() > 2500
+    g = n2v.Graph.from_csr(cg, p, q, rng="philox", seed=77)
+    g.preprocess_transition_probs()
+    a = g.simulate_walks(1, 30)
+    g.force_on_the_fly = True
+    b = g.simulate_walks_on_the_fly(1, 30)
+    assert torch.equal(a.lens, b.lens) and torch.equal(a.walks, b.walks)
+    # parity stream + start subset through the scratch path
+    g.rng = "numpy"
+    sub = cg.labels[cg.start_order[:500]].tolist() + [5, 17]
+    np.random.seed(3)
+    c = g.simulate_walks_on_the_fly(2, 12, nodes=sub)
+    g.force_on_the_fly = False
+    np.random.seed(3)
+    d = g.simulate_walks(2, 12, nodes=sub)
+    assert torch.equal(c.walks, d.walks) and torch.equal(c.lens, d.lens)
+
+
+def test_on_the_fly_zero_weight_raises(n2v):
+    import networkx as nx
+    G = nx.Graph()
+    G.add_edge(0, 1, weight=0.0)
+    G.add_edge(1, 2, weight=0.0)
+    g = n2v.Graph(G, False, 0.5, 2)
+    with pytest.raises(ZeroDivisionError):
+        g.simulate_walks_on_the_fly(1, 5)
