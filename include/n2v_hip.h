@@ -115,6 +115,32 @@ int n2v_walk(const int64_t* row_ptr, const n2v_alias_slot* node_slots, const n2v
              int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
              int32_t* walks, int32_t* lens, void* stream);
 
+/* "Fat" alias slot (32 B, 32-B aligned): q plus the walk records of both outcomes of the draw
+ * (keep = neighbour k, alias = neighbour J[k]), each {40-bit table index, 24-bit degree, node
+ * id} as in n2v_edge_rec without the row base.  One aligned 32-B gather per walk step instead
+ * of two dependent 16-B gathers, at 2x the table memory.                                   */
+typedef struct n2v_fat_slot {
+    double q;
+    uint32_t keep_slot_lo, keep_deg_hi, keep_dst;
+    uint32_t alias_slot_lo, alias_deg_hi, alias_dst;
+} n2v_fat_slot;
+
+/* Expand thin tables into fat ones.  Table i occupies slots [tab_off[i], tab_off[i+1]) of
+ * `thin` and of `fat` and draws from the row of node tab_node[i] (tab_node == NULL: node i —
+ * the node tables with tab_off = row_ptr; edge tables: tab_off = edge_off, tab_node = col).
+ * `recs` are the thin walk records (their 40-bit indices address `fat` identically).        */
+int n2v_build_fat_slots(int64_t n_tables, const int64_t* tab_off, const int32_t* tab_node,
+                        const int64_t* row_ptr, const n2v_alias_slot* thin, const n2v_edge_rec* recs,
+                        n2v_fat_slot* fat, void* stream);
+
+/* n2v_walk over fat tables: identical output.  node_fat: fat node tables (slot k of node v at
+ * row_ptr[v]+k); fat: the array the records' table indices address.                         */
+int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat, const n2v_fat_slot* fat,
+                 const int32_t* starts, int64_t n_starts, int64_t pos_begin, int64_t pos_count,
+                 int64_t round_begin, int64_t round_count, int32_t walk_length, int32_t rng_mode,
+                 const double* uniforms, const int64_t* walk_uoff, uint64_t seed, int32_t* walks,
+                 int32_t* lens, void* stream);
+
 /* simulate_walks_on_the_fly / node2vec_walk_on_the_fly (src/node2vec.py:13-53,97-111): the
  * same walk with the (prev, cur) table rebuilt at every step instead of read from the edge
  * tables (for graphs whose sum of deg^2 slots does not fit in HBM).  Output is identical to

@@ -1,0 +1,182 @@
+// "Fat slot" walk — gfx950 (MI355X): one 32-byte gather per step.
+//
+// Same walk as n2v_walk (src/node2vec.py:55-95, :271-281) over a table layout that spends
+// HBM capacity to halve the number of memory requests: alias slot k of a table carries, next
+// to q, the walk records of BOTH outcomes of the draw (neighbour k and neighbour J[k]):
+//
+//     fat = fat_slots[table + floor(u1*K)];          one aligned 32-B load
+//     rec = (u2 < fat.q) ? fat.keep : fat.alias;     (:278-281)
+//     table = rec.slot, K = rec.deg, node = rec.dst
+//
+// The thin layout costs two dependent 16-B gathers per step and is bound by the chip's
+// random-request rate (each gather is one 64-B request); a 32-B aligned slot
+// never straddles a 64-B line, so a step is one request.  Memory: 32 B per alias slot, i.e.
+// 2x the thin tables (C3: 58.5 GB) — the reason this layout only makes sense on a 288 GB part.
+// Tables are expanded from the thin, reference-exact tables, so the walks are bit-identical.
+#include "n2v_common.h"
+
+namespace {
+
+struct FatArgs {
+    const int64_t* row_ptr;
+    const n2v_fat_slot* node_fat;
+    const n2v_fat_slot* fat;
+    const int32_t* starts;
+    int64_t n_starts, pos_begin, pos_count, round_begin, n_local;
+    int32_t L;
+    const double* uniforms;
+    const int64_t* walk_uoff;
+    uint64_t seed;
+    int32_t* walks;
+    int32_t* lens;
+};
+
+__device__ __forceinline__ void philox_uniforms(uint64_t seed, uint64_t walk, uint32_t step, double& u1, double& u2) {
+    uint32_t c0 = (uint32_t)walk, c1 = (uint32_t)(walk >> 32), c2 = step, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u1 = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
+    u2 = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) / 9007199254740992.0;
+}
+
+template <int RNG, bool VEC4>
+__global__ void __launch_bounds__(256) walk_fat_kernel(FatArgs a) {
+    const int64_t lw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (lw >= a.n_local) return;
+    const int64_t rl = lw / a.pos_count, pl = lw - rl * a.pos_count;
+    const uint64_t gw = (uint64_t)((a.round_begin + rl) * a.n_starts + a.pos_begin + pl);
+    const int32_t L = a.L;
+    const int32_t cur0 = a.starts[a.pos_begin + pl];
+    const int64_t b0 = a.row_ptr[cur0], b1 = a.row_ptr[cur0 + 1];
+    const n2v_fat_slot* tab = a.node_fat + b0;  // first step: node table (:69-70)
+    uint32_t K = (uint32_t)(b1 - b0);
+    int32_t len = 1;
+    uint32_t t = 0;
+    const double* up = nullptr;
+    if (RNG == N2V_RNG_UNIFORMS) up = a.uniforms + (a.walk_uoff ? a.walk_uoff[lw] : (int64_t)2 * (L - 1) * lw);
+
+    auto step = [&]() -> int32_t {
+        if (K == 0) return -1;  // dead end: stop, consume nothing (:76-77)
+        double u1, u2;
+        if (RNG == N2V_RNG_UNIFORMS) {
+            const double2 u = *reinterpret_cast<const double2*>(up + 2 * (int64_t)t);
+            u1 = u.x; u2 = u.y;
+        } else {
+            philox_uniforms(a.seed, gw, t, u1, u2);
+        }
+        ++t;
+        const uint32_t kk = (uint32_t)(u1 * (double)K);  // :277
+        const uint4* p = reinterpret_cast<const uint4*>(tab + kk);
+        const uint4 lo = p[0], hi = p[1];  // {q.lo, q.hi, keep.slot_lo, keep.deg_hi | keep.dst, alias.slot_lo, alias.deg_hi, alias.dst}
+        const double q = __hiloint2double((int)lo.y, (int)lo.x);
+        const bool keep = u2 < q;  // :278
+        const uint32_t slot_lo = keep ? lo.z : hi.y;
+        const uint32_t deg_hi = keep ? lo.w : hi.z;
+        const uint32_t dst = keep ? hi.x : hi.w;
+        tab = a.fat + (((uint64_t)(deg_hi >> 24) << 32) | slot_lo);
+        K = deg_hi & 0xFFFFFFu;
+        ++len;
+        return (int32_t)dst;
+    };
+
+    int32_t* out = a.walks + lw * (int64_t)L;
+    if (VEC4) {
+        int4 o;
+        o.x = cur0; o.y = step(); o.z = step(); o.w = step();
+        *reinterpret_cast<int4*>(out) = o;
+        for (int32_t g = 4; g < L; g += 4) {
+            o.x = step(); o.y = step(); o.z = step(); o.w = step();
+            *reinterpret_cast<int4*>(out + g) = o;
+        }
+    } else {
+        out[0] = cur0;
+        for (int32_t i = 1; i < L; ++i) out[i] = step();
+    }
+    a.lens[lw] = len;
+}
+
+// One wavefront expands one table: fat[t+k] = {thin[t+k].q, rec(base+k), rec(base+J[k])} where
+// base = row_ptr[node the table draws from] and rec(e) is the thin walk record of CSR entry e.
+__global__ void __launch_bounds__(256)
+fat_expand_kernel(int64_t n_tables, const int64_t* __restrict__ tab_off, const int32_t* __restrict__ tab_node,
+                  const int64_t* __restrict__ row_ptr, const n2v_alias_slot* __restrict__ thin,
+                  const n2v_edge_rec* __restrict__ recs, n2v_fat_slot* __restrict__ fat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tb = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (tb >= n_tables) return;
+    const int64_t t0 = tab_off[tb];
+    const int32_t node = tab_node ? tab_node[tb] : (int32_t)tb;
+    const int64_t base = row_ptr[node];
+    const int K = (int)(row_ptr[node + 1] - base);
+    for (int k = lane; k < K; k += 64) {
+        const n2v_alias_slot s = thin[t0 + k];
+        const uint4 ra = *reinterpret_cast<const uint4*>(recs + base + k);
+        const uint4 rb = *reinterpret_cast<const uint4*>(recs + base + s.J);
+        uint4 lo, hi;  // rec = {slot_lo, base, dst, deg_hi}; the row base is not needed any more
+        lo.x = (uint32_t)__double2loint(s.q);
+        lo.y = (uint32_t)__double2hiint(s.q);
+        lo.z = ra.x; lo.w = ra.w;
+        hi.x = ra.z;
+        hi.y = rb.x; hi.z = rb.w; hi.w = rb.z;
+        uint4* o = reinterpret_cast<uint4*>(fat + t0 + k);
+        o[0] = lo;
+        o[1] = hi;
+    }
+}
+
+}  // namespace
+
+extern "C" int n2v_build_fat_slots(int64_t n_tables, const int64_t* tab_off, const int32_t* tab_node,
+                                   const int64_t* row_ptr, const n2v_alias_slot* thin, const n2v_edge_rec* recs,
+                                   n2v_fat_slot* fat, void* stream) {
+    if (n_tables < 0) return n2v::fail(N2V_ERR_INVALID, "n2v_build_fat_slots: negative count");
+    if (n_tables == 0) return N2V_OK;
+    if (!tab_off || !row_ptr || !thin || !recs || !fat)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_build_fat_slots: null pointer");
+    if (((uintptr_t)fat & 31) != 0) return n2v::fail(N2V_ERR_INVALID, "n2v_build_fat_slots: fat slots not 32-byte aligned");
+    const int64_t blocks = (n_tables + 3) / 4;
+    if (blocks > 0x7fffffff) return n2v::fail(N2V_ERR_INVALID, "n2v_build_fat_slots: too many tables in one call");
+    hipLaunchKernelGGL(fat_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_tables, tab_off,
+                       tab_node, row_ptr, thin, recs, fat);
+    return n2v::check_launch("n2v_build_fat_slots");
+}
+
+extern "C" int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat, const n2v_fat_slot* fat,
+                            const int32_t* starts, int64_t n_starts, int64_t pos_begin, int64_t pos_count,
+                            int64_t round_begin, int64_t round_count, int32_t walk_length, int32_t rng_mode,
+                            const double* uniforms, const int64_t* walk_uoff, uint64_t seed, int32_t* walks,
+                            int32_t* lens, void* stream) {
+    if (pos_count < 0 || round_count < 0 || pos_begin < 0 || round_begin < 0 || walk_length < 1 ||
+        pos_begin + pos_count > n_starts)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_fat: bad shard or length");
+    const int64_t n_local = pos_count * round_count;
+    if (n_local == 0) return N2V_OK;
+    if (!row_ptr || !node_fat || !starts || !lens || !walks || (walk_length > 1 && !fat))
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_fat: null pointer");
+    if (rng_mode != N2V_RNG_UNIFORMS && rng_mode != N2V_RNG_PHILOX)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_fat: rng_mode %d", (int)rng_mode);
+    if (rng_mode == N2V_RNG_UNIFORMS && walk_length > 1 && !uniforms)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_fat: parity mode needs a uniform buffer");
+    if (((uintptr_t)uniforms & 15) != 0 || ((uintptr_t)node_fat & 31) != 0 || ((uintptr_t)fat & 31) != 0)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_fat: misaligned buffer");
+    if (n_local > (int64_t)0x7fffffff * 256) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_fat: too many walks in one call");
+    FatArgs a{row_ptr, node_fat, fat, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
+              uniforms, walk_uoff, seed, walks, lens};
+    const bool vec4 = walk_length >= 4 && (walk_length % 4) == 0 && ((uintptr_t)walks & 15) == 0;
+    const dim3 grid(n2v::grid_for(n_local, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (rng_mode == N2V_RNG_UNIFORMS) {
+        if (vec4) hipLaunchKernelGGL((walk_fat_kernel<N2V_RNG_UNIFORMS, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((walk_fat_kernel<N2V_RNG_UNIFORMS, false>), grid, block, 0, st, a);
+    } else {
+        if (vec4) hipLaunchKernelGGL((walk_fat_kernel<N2V_RNG_PHILOX, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((walk_fat_kernel<N2V_RNG_PHILOX, false>), grid, block, 0, st, a);
+    }
+    return n2v::check_launch("n2v_walk_fat");
+}

@@ -11,6 +11,7 @@ from . import _lib
 from .csr import CsrGraph
 
 SLOT_BYTES = 16  # sizeof(n2v_alias_slot)
+FAT_BYTES = 32   # sizeof(n2v_fat_slot)
 
 
 def _require_gpu(device):
@@ -40,13 +41,14 @@ class WalkEngine:
         self.edge_slots = None
         self.edge_off = None
         self.recs = None
+        self.node_fat = self.edge_fat = None
         self.first_order = False
 
     # ------------------------------------------------------------------ tables
     def _stream(self):
         return _lib.stream_ptr(self.device)
 
-    def preprocess(self, first_order_shortcut=True):
+    def preprocess(self, first_order_shortcut=True, fat="auto"):
         """preprocess_transition_probs (src/node2vec.py:176-204) on device.
 
         With p == q == 1 every (src,dst) table is bit-identical to dst's node table
@@ -94,6 +96,29 @@ class WalkEngine:
             self.node_slots = self.edge_slots = self.recs = None
             raise ZeroDivisionError("float division by zero")
         self.total_slots = total
+        self.node_fat = self.edge_fat = None
+        if fat == "auto":
+            free, _ = torch.cuda.mem_get_info(d)
+            fat = (nnz + (0 if self.first_order else total)) * FAT_BYTES < free - (8 << 30)
+        if fat and nnz > 0:
+            self.build_fat()
+
+    def build_fat(self):
+        """Expand the thin tables into 32-byte fat slots (one gather per walk step)."""
+        csr, d = self.csr, self.device
+        N, nnz = csr.n_nodes, csr.nnz
+        with torch.cuda.device(d):
+            self.node_fat = torch.empty((max(nnz, 1), 4), dtype=torch.int64, device=d)
+            _lib.check(self.lib.n2v_build_fat_slots(
+                N, _lib.ptr(self.row_ptr), None, _lib.ptr(self.row_ptr), _lib.ptr(self.node_slots),
+                _lib.ptr(self.recs), _lib.ptr(self.node_fat), self._stream()))
+            if self.first_order:
+                self.edge_fat = self.node_fat
+            else:
+                self.edge_fat = torch.empty((max(self.total_slots, 1), 4), dtype=torch.int64, device=d)
+                _lib.check(self.lib.n2v_build_fat_slots(
+                    nnz, _lib.ptr(self.edge_off), _lib.ptr(self.col), _lib.ptr(self.row_ptr),
+                    _lib.ptr(self.edge_slots), _lib.ptr(self.recs), _lib.ptr(self.edge_fat), self._stream()))
 
     @property
     def ready(self):
@@ -130,7 +155,7 @@ class WalkEngine:
 
     # ------------------------------------------------------------------ walks
     def walk(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
-             pos_begin=0, pos_count=None, round_begin=0, out=None):
+             pos_begin=0, pos_count=None, round_begin=0, out=None, layout=None):
         """Launch the walk kernel.  ``starts``: int32 device tensor of dense ids (the
         start order).  Returns (walks int32[n_local, L], lens int32[n_local]) on device."""
         if not self.ready:
@@ -151,11 +176,20 @@ class WalkEngine:
                 walks, lens = out
                 assert walks.shape == (n_local, L) and walks.dtype == torch.int32 and walks.is_contiguous()
             mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
-            _lib.check(self.lib.n2v_walk(
-                _lib.ptr(self.row_ptr), _lib.ptr(self.node_slots), _lib.ptr(self.recs),
-                _lib.ptr(self.edge_slots), _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin,
-                num_rounds, L, mode, _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1),
-                _lib.ptr(walks), _lib.ptr(lens), self._stream()))
+            use_fat = self.edge_fat is not None if layout is None else (layout == "fat")
+            if use_fat:
+                if self.edge_fat is None:
+                    raise RuntimeError("fat tables were not built")
+                _lib.check(self.lib.n2v_walk_fat(
+                    _lib.ptr(self.row_ptr), _lib.ptr(self.node_fat), _lib.ptr(self.edge_fat), _lib.ptr(starts),
+                    n_starts, pos_begin, pos_count, round_begin, num_rounds, L, mode, _lib.ptr(uniforms),
+                    _lib.ptr(walk_uoff), int(seed) & (2**64 - 1), _lib.ptr(walks), _lib.ptr(lens), self._stream()))
+            else:
+                _lib.check(self.lib.n2v_walk(
+                    _lib.ptr(self.row_ptr), _lib.ptr(self.node_slots), _lib.ptr(self.recs),
+                    _lib.ptr(self.edge_slots), _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin,
+                    num_rounds, L, mode, _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1),
+                    _lib.ptr(walks), _lib.ptr(lens), self._stream()))
         return walks, lens
 
 

@@ -49,3 +49,79 @@ def get_roc_score(vectors, edges_pos, edges_neg):
     pos = cosine_scores(vectors, torch.as_tensor(np.asarray(edges_pos), dtype=torch.int64, device=d))
     neg = cosine_scores(vectors, torch.as_tensor(np.asarray(edges_neg), dtype=torch.int64, device=d))
     return roc_auc(pos, neg), average_precision(pos, neg)
+
+
+# --------------------------------------------------------------------------- the main_link flow
+def split_edges(edges, test_ratio=0.5, seed=123):
+    """src/main_link.py:525-526 with src/settings.py:1-2: sklearn's train_test_split on the
+    (u, v) edge array (TEST_RATIO 0.5, RANDOM_SEED 123)."""
+    from sklearn.model_selection import train_test_split
+    tr, te = train_test_split(np.asarray(edges), test_size=test_ratio, random_state=seed)
+    return tr, te
+
+
+def build_neg_samples(labels, true_edges, seed=0):
+    """src/main_link.py:191-204: as many distinct non-edges (a < b) as there are edges, drawn
+    uniformly over node pairs — vectorised rejection sampling so 10^7 edges do not go through
+    a Python loop; the reference's `random.sample` is unseeded, a seed is taken here."""
+    labels = np.asarray(labels, dtype=np.int64)
+    e = np.asarray(true_edges, dtype=np.int64).reshape(-1, 2)
+    n = len(labels)
+    ia, ib = np.searchsorted(labels, e[:, 0]), np.searchsorted(labels, e[:, 1])
+    true_key = np.unique(np.minimum(ia, ib) * n + np.maximum(ia, ib))
+    want = len(true_key)
+    rs = np.random.RandomState(seed)
+    got = np.zeros(0, dtype=np.int64)
+    while len(got) < want:
+        k = int((want - len(got)) * 1.3) + 64
+        a, b = rs.randint(0, n, size=k), rs.randint(0, n, size=k)
+        key = np.minimum(a, b) * np.int64(n) + np.maximum(a, b)
+        key = key[a != b]
+        key = key[~np.isin(key, true_key, assume_unique=False)]
+        got = np.unique(np.concatenate([got, key]))
+        if len(got) > want:
+            got = rs.permutation(got)[:want]
+    return np.stack([labels[got // n], labels[got % n]], 1)
+
+
+def run(edges, p=1.0, q=1.0, num_walks=5, walk_length=40, dimensions=128, window_size=10, iter=1,
+        directed=False, test_ratio=0.5, split_seed=123, neg_seed=0, rng="philox", seed=1, device=None):
+    """The AUC path of src/main_link.py:519-563 (defaults of src/settings.py: 5 walks of length
+    40, d=128): split the edges 50/50, walk and embed on the TRAINING graph only (nodes isolated
+    by the removal keep their length-1 walks), score test edges against sampled non-edges of
+    the full graph by cosine similarity.  Returns {'roc': ..., 'ap': ..., ...}."""
+    import node2vec
+    from . import csr, sgns
+    edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    full = csr.from_edges(edges[:, 0], edges[:, 1], None, directed)
+    tr, te = split_edges(edges, test_ratio, split_seed)
+    # nx_G.remove_edges_from(test_edges): the node set (and its order) stays the full graph's
+    train = csr.from_edges(tr[:, 0], tr[:, 1], None, directed)
+    missing = np.setdiff1d(full.labels, train.labels)
+    if len(missing):
+        train = _with_isolated_nodes(train, full)
+    g = node2vec.Graph.from_csr(train, p, q, device=device, rng=rng, seed=seed)
+    g.preprocess_transition_probs()
+    corpus = g.simulate_walks(num_walks, walk_length)
+    model = sgns.SgnsModel(train.n_nodes, dim=dimensions, window=window_size, seed=seed, device=corpus.walks.device)
+    model.build_vocab(corpus.walks)
+    sgns.train(model, corpus.walks, corpus.lens, epochs=iter)
+    neg = build_neg_samples(full.labels, edges, neg_seed)
+    te_d = np.stack([train.dense_of(te[:, 0]), train.dense_of(te[:, 1])], 1)
+    neg_d = np.stack([train.dense_of(neg[:, 0]), train.dense_of(neg[:, 1])], 1)
+    roc, ap = get_roc_score(model.vectors(), te_d, neg_d)
+    return {"roc": roc, "ap": ap, "n_nodes": int(full.n_nodes), "n_train": int(len(tr)), "n_test": int(len(te)),
+            "pairs_trained": model.pairs_trained(), "model": model, "graph": g}
+
+
+def _with_isolated_nodes(train, full):
+    """Re-express the training CSR over the full graph's node set (same labels / start order),
+    so nodes that lost all their edges stay in the graph with degree 0."""
+    from .csr import CsrGraph
+    pos = np.searchsorted(full.labels, train.labels)
+    deg = np.zeros(full.n_nodes, dtype=np.int64)
+    deg[pos] = np.diff(train.row_ptr)
+    row_ptr = np.zeros(full.n_nodes + 1, dtype=np.int64)
+    np.cumsum(deg, out=row_ptr[1:])
+    col = pos[train.col].astype(np.int32)   # rows stay sorted: pos is increasing
+    return CsrGraph(full.labels, row_ptr, col, train.w, full.start_order, train.directed)

@@ -196,6 +196,17 @@ def test_tables_and_walks_vs_c_oracle_20k(n2v, weighted, directed, p, q):
     chk = np.random.RandomState(42)
     chk.random_sample(nd)
     assert np.random.random_sample() == chk.random_sample()
+    # both table layouts (16-B slots + records, 32-B fat slots) give the same walks
+    assert eng.edge_fat is not None
+    tw, tl = eng.walk(eng.start_order, 2, L, rng="philox", seed=0xC0FFEE1234, layout="thin")
+    fw, fl = eng.walk(eng.start_order, 2, L, rng="philox", seed=0xC0FFEE1234, layout="fat")
+    ow2, ol2, _ = co.walk(cg.start_order, 2, L, mode="philox", seed=0xC0FFEE1234)
+    assert torch.equal(tw, fw) and torch.equal(tl, fl)
+    assert np.array_equal(tw.cpu().numpy(), ow2) and np.array_equal(tl.cpu().numpy(), ol2)
+    U = torch.rand(2 * (L - 1) * cg.n_nodes, dtype=torch.float64, device=eng.device)
+    tw, tl = eng.walk(eng.start_order, 1, L, rng="uniforms", uniforms=U, layout="thin")
+    fw, fl = eng.walk(eng.start_order, 1, L, rng="uniforms", uniforms=U, layout="fat")
+    assert torch.equal(tw, fw) and torch.equal(tl, fl)
     # sharding by start position and by round reproduces the same rows
     g.rng = "philox"
     full_w, full_l = eng.walk(eng.start_order, 2, L, rng="philox", seed=9)

@@ -122,3 +122,21 @@ def test_replica_merge_over_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_build_neg_samples_and_isolated_nodes():
+    from n2v_hip import csr, linkpred
+    rs = np.random.RandomState(0)
+    labels = np.arange(0, 400, 2)                                     # 200 nodes, even labels
+    e = labels[rs.randint(0, 200, size=(3000, 2))]
+    e = e[e[:, 0] != e[:, 1]]
+    neg = linkpred.build_neg_samples(labels, e, seed=1)
+    true = set((min(a, b), max(a, b)) for a, b in e.tolist())
+    assert len(neg) == len(true)
+    got = set(map(tuple, neg.tolist()))
+    assert len(got) == len(neg) and not (got & true) and all(a < b for a, b in got)
+    full = csr.from_edges([0, 2, 4, 6], [2, 4, 0, 8])
+    train = csr.from_edges([0, 2], [2, 4])                             # 6 and 8 lost their edges
+    t2 = linkpred._with_isolated_nodes(train, full)
+    assert t2.n_nodes == 5 and t2.degrees.tolist() == [1, 2, 1, 0, 0]
+    assert t2.labels[t2.col].tolist() == [2, 0, 4, 2] and np.array_equal(t2.start_order, full.start_order)
