@@ -266,3 +266,14 @@ def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, G):
     auc_cpu, _ = linkpred.get_roc_score(torch.from_numpy(syn0).cuda(), te_d, neg_d)
     print("G=%d syncs=%d: AUC %.5f vs sequential CPU %.5f" % (G, n_syncs, auc, auc_cpu))
     assert abs(auc - auc_cpu) <= AUC_BAND, (G, n_syncs, auc, auc_cpu)
+
+
+def test_main_link_flow_end_to_end(torch_cuda):
+    """src/main_link.py:519-563 flow on the device (split 50/50 seed 123, walk + embed on the
+    training graph, cosine AUC/AP on test edges vs sampled non-edges), settings.py defaults."""
+    from n2v_hip import linkpred
+    edges = _planted_partition(n=2000, k=20, m_in=16000, m_out=3000, seed=3)
+    res = linkpred.run(edges, p=1.0, q=1.0, num_walks=5, walk_length=40, dimensions=128, window_size=10)
+    assert res["n_train"] + res["n_test"] == len(edges) and abs(res["n_train"] - res["n_test"]) <= 1
+    assert 0.8 < res["roc"] <= 1.0 and 0.7 < res["ap"] <= 1.0, (res["roc"], res["ap"])
+    print("main_link flow: AUC %.4f AP %.4f" % (res["roc"], res["ap"]))
