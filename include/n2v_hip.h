@@ -141,6 +141,21 @@ int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat, const n2v
                  const double* uniforms, const int64_t* walk_uoff, uint64_t seed, int32_t* walks,
                  int32_t* lens, void* stream);
 
+/* numpy's legacy MT19937 stream (np.random.rand(), src/node2vec.py:277-278) on the device.
+ * n2v_mt19937_jump_host: pure host arithmetic.  key_host: the 624 state words of
+ * np.random.get_state(); states_host[k] (k < n_streams, 624 words each) receives the state
+ * window advanced by k * stride_words outputs (polynomial jump-ahead), states_host[0] = key.
+ * n2v_mt19937_fill: stream k (one wavefront) writes the doubles random_sample() would return
+ * for outputs [k*words_per_stream, (k+1)*words_per_stream) of the sequence that starts at
+ * position `pos` (0..624) of the caller's state, n_doubles in total, to out[] in order.
+ * states: DEVICE copy of states_host; words_per_stream even, n_streams*words_per_stream >=
+ * 2*n_doubles.  final_state (device uint32[625], may be NULL): key words + pos after the last
+ * draw, i.e. what np.random.get_state() would hold after n_doubles random_sample() calls.   */
+int n2v_mt19937_jump_host(const uint32_t* key_host, int64_t stride_words, int32_t n_streams,
+                          uint32_t* states_host);
+int n2v_mt19937_fill(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
+                     int64_t n_doubles, double* out, uint32_t* final_state, void* stream);
+
 /* simulate_walks_on_the_fly / node2vec_walk_on_the_fly (src/node2vec.py:13-53,97-111): the
  * same walk with the (prev, cur) table rebuilt at every step instead of read from the edge
  * tables (for graphs whose sum of deg^2 slots does not fit in HBM).  Output is identical to

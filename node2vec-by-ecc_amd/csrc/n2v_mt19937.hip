@@ -1,0 +1,287 @@
+// numpy's legacy MT19937 `random_sample` stream, generated on the device — gfx950 (MI355X).
+//
+// The reference draws its walk uniforms from numpy's GLOBAL MT19937 state
+// (np.random.rand() twice per step, src/node2vec.py:277-278).  Parity mode must consume that
+// exact stream; generating it with numpy on the host and uploading it caps the whole walk at
+// the host's ~2e8 doubles/s.  MT19937 is a linear recurrence over GF(2), so the stream can be
+// cut into P contiguous pieces whose start states are obtained by polynomial jump-ahead
+// (Haramoto, Matsumoto, Nishimura, Panneton, L'Ecuyer 2008):
+//
+//   window_k = A^(k*S) window_0 = g_k(A) window_0,  g_k(x) = x^(k*S) mod (x * phi(x))
+//
+// where `window` is 624 consecutive words of the sequence, A slides it by one word, phi is the
+// degree-19937 minimal polynomial of the sequence (found once by Berlekamp-Massey) and the
+// extra factor x makes the identity hold on all 19968 bits of a window (the low 31 bits of
+// its oldest word are outside the 19937-bit state but may still have to be output).
+// Host code below does the GF(2) polynomial work (a few ms per stream); the kernel then runs
+// numpy's own algorithm — lazy block twist, tempering, (a>>5, b>>6) -> double — one wavefront
+// per stream with the 624-word window in LDS, and hands back the final (key, pos) so the
+// caller can leave numpy's global state exactly where the reference would have left it.
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "n2v_common.h"
+
+namespace {
+
+constexpr int kN = 624, kM = 397;
+constexpr uint32_t kMatrixA = 0x9908b0dfu, kUpper = 0x80000000u, kLower = 0x7fffffffu;
+constexpr int kDeg = 19937;               // degree of phi
+constexpr int kModDeg = kDeg + 1;         // modulus x*phi(x)
+constexpr int kPW = 312;                  // 64-bit words per reduced polynomial (19968 bits)
+
+// ------------------------------------------------------------------ host: sliding window
+struct Window {  // logical word j = w[(head + j) % 624]
+    uint32_t w[kN];
+    int head;
+};
+
+inline void window_step(Window& s) {  // A: drop x_k, append x_{k+624}
+    const int i0 = s.head, i1 = (s.head + 1) % kN, im = (s.head + kM) % kN;
+    const uint32_t y = (s.w[i0] & kUpper) | (s.w[i1] & kLower);
+    s.w[i0] = s.w[im] ^ (y >> 1) ^ ((y & 1u) ? kMatrixA : 0u);
+    s.head = i1;
+}
+
+inline void window_xor(Window& a, const uint32_t* b_logical) {
+    const int first = kN - a.head;  // logical 0..first-1 live at w[head..623], the rest at w[0..head-1]
+    for (int j = 0; j < first; ++j) a.w[a.head + j] ^= b_logical[j];
+    for (int j = first; j < kN; ++j) a.w[j - first] ^= b_logical[j];
+}
+
+// ------------------------------------------------------------------ host: GF(2)[x]
+typedef std::vector<uint64_t> Poly;  // little-endian bits
+
+inline bool pbit(const Poly& p, int i) { return (p[i >> 6] >> (i & 63)) & 1ULL; }
+
+// r ^= b << sh   (b has nb words)
+inline void xor_shifted(uint64_t* r, const uint64_t* b, int nb, int sh) {
+    const int ws = sh >> 6, bs = sh & 63;
+    if (bs == 0) {
+        for (int i = 0; i < nb; ++i) r[ws + i] ^= b[i];
+    } else {
+        uint64_t carry = 0;
+        for (int i = 0; i < nb; ++i) {
+            r[ws + i] ^= (b[i] << bs) | carry;
+            carry = b[i] >> (64 - bs);
+        }
+        r[ws + nb] ^= carry;
+    }
+}
+
+struct Mt {
+    Poly mod;  // x * phi(x), degree kModDeg, kPW+1 words
+    bool ready = false;
+    std::mutex mu;
+};
+Mt g_mt;
+
+// minimal polynomial of the MT19937 bit stream by Berlekamp-Massey (2*19937 bits suffice)
+void build_modulus() {
+    std::lock_guard<std::mutex> lk(g_mt.mu);
+    if (g_mt.ready) return;
+    const int nbits = 2 * kDeg + 64;
+    Window s;
+    s.w[0] = 5489u;  // any non-degenerate seed: init_genrand(5489)
+    for (int i = 1; i < kN; ++i) s.w[i] = 1812433253u * (s.w[i - 1] ^ (s.w[i - 1] >> 30)) + (uint32_t)i;
+    s.head = 0;
+    const int W = (kDeg + 64) / 64 + 2;
+    std::vector<uint64_t> C(W, 0), B(W, 0), T(W, 0), R(W, 0);
+    C[0] = B[0] = 1;
+    int L = 0, m = 1;
+    for (int N = 0; N < nbits; ++N) {
+        window_step(s);
+        const uint64_t bit = s.w[(s.head + kN - 1) % kN] & 1u;  // newest word's LSB
+        // R: bit i = b_{N-i}
+        uint64_t carry = bit;
+        for (int i = 0; i < W; ++i) {
+            const uint64_t nc = R[i] >> 63;
+            R[i] = (R[i] << 1) | carry;
+            carry = nc;
+        }
+        uint64_t acc = 0;
+        const int lw = L / 64 + 1;
+        for (int i = 0; i < lw && i < W; ++i) acc ^= C[i] & R[i];
+        if (__builtin_parityll(acc)) {
+            if (2 * L <= N) {
+                T = C;
+                xor_shifted(C.data(), B.data(), W - (m >> 6) - 2, m);
+                L = N + 1 - L;
+                B = T;
+                m = 1;
+            } else {
+                xor_shifted(C.data(), B.data(), W - (m >> 6) - 2, m);
+                ++m;
+            }
+        } else {
+            ++m;
+        }
+    }
+    // phi(x) = x^L * C(1/x); modulus = x * phi(x)
+    Poly mod(kPW + 1, 0);
+    if (L == kDeg) {
+        for (int i = 0; i <= L; ++i)
+            if ((C[i >> 6] >> (i & 63)) & 1ULL) {
+                const int e = L - i + 1;  // +1: times x
+                mod[e >> 6] |= 1ULL << (e & 63);
+            }
+        g_mt.mod = mod;
+        g_mt.ready = true;
+    }
+}
+
+// r = a * b mod M   (a, b reduced: degree < kModDeg)
+void mulmod(const Poly& a, const Poly& b, Poly& r) {
+    std::vector<uint64_t> t(2 * kPW + 2, 0);
+    for (int i = 0; i < kModDeg; ++i)
+        if (pbit(a, i)) xor_shifted(t.data(), b.data(), kPW, i);
+    const Poly& M = g_mt.mod;
+    for (int d = 2 * kModDeg; d >= kModDeg; --d)
+        if ((t[d >> 6] >> (d & 63)) & 1ULL) xor_shifted(t.data(), M.data(), kPW + 1, d - kModDeg);
+    r.assign(t.begin(), t.begin() + kPW);
+}
+
+// x^n mod M
+Poly powmod_x(uint64_t n) {
+    Poly r(kPW, 0), t;
+    r[0] = 1;
+    if (n == 0) return r;
+    int top = 63;
+    while (!((n >> top) & 1ULL)) --top;
+    for (int b = top; b >= 0; --b) {
+        mulmod(r, r, t);
+        r.swap(t);
+        if ((n >> b) & 1ULL) {  // times x: shift by one and reduce once
+            uint64_t carry = 0;
+            for (int i = 0; i < kPW; ++i) {
+                const uint64_t nc = r[i] >> 63;
+                r[i] = (r[i] << 1) | carry;
+                carry = nc;
+            }
+            if (pbit(r, kModDeg)) {
+                for (int i = 0; i < kPW; ++i) r[i] ^= g_mt.mod[i];
+                // bit kModDeg lies inside word kModDeg>>6 < kPW, cleared by the xor above
+            }
+        }
+    }
+    return r;
+}
+
+// out = g(A) in  (Horner); windows as 624 logical words
+void apply_poly(const Poly& g, const uint32_t* in, uint32_t* out) {
+    Window h;
+    std::memset(h.w, 0, sizeof(h.w));
+    h.head = 0;
+    int deg = kModDeg - 1;
+    while (deg > 0 && !pbit(g, deg)) --deg;
+    for (int i = deg; i >= 0; --i) {
+        window_step(h);
+        if (pbit(g, i)) window_xor(h, in);
+    }
+    for (int j = 0; j < kN; ++j) out[j] = h.w[(h.head + j) % kN];
+}
+
+// ------------------------------------------------------------------ device: one wave per stream
+__device__ __forceinline__ uint32_t temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__global__ void __launch_bounds__(64)
+mt_fill_kernel(const uint32_t* __restrict__ states, int pos0, int64_t words_per_stream, int64_t total_words,
+               double* __restrict__ out, uint32_t* __restrict__ final_state) {
+    __shared__ uint32_t mt[kN];
+    __shared__ uint32_t carry_word;
+    const int lane = threadIdx.x;
+    const int64_t k = blockIdx.x;
+    for (int i = lane; i < kN; i += 64) mt[i] = states[k * kN + i];
+    __syncthreads();
+    int pos = pos0;
+    int64_t produced = k * words_per_stream;
+    const int64_t w_end = min(total_words, produced + words_per_stream);
+    while (produced < w_end) {
+        if (pos >= kN) {
+            // numpy's block twist, in place, 64 consecutive words at a time (every word a chunk
+            // needs from a later index is still old, everything from an earlier index is new)
+            for (int c = 0; c < kN; c += 64) {
+                const int i = c + lane;
+                uint32_t v = 0;
+                if (i < kN) {
+                    const uint32_t y = (mt[i] & kUpper) | (mt[(i + 1) % kN] & kLower);
+                    v = mt[(i + kM) % kN] ^ (y >> 1) ^ ((y & 1u) ? kMatrixA : 0u);
+                }
+                __syncthreads();
+                if (i < kN) mt[i] = v;
+                __syncthreads();
+            }
+            pos = 0;
+        }
+        const int take = (int)min((int64_t)(kN - pos), w_end - produced);
+        // stream word j = produced + idx sits in mt[pos + idx]; even j = first half of a double
+        const int odd = (int)(produced & 1);
+        if (odd && lane == 0) {
+            const uint32_t a = carry_word >> 5, b = temper(mt[pos]) >> 6;
+            out[(produced - 1) >> 1] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        }
+        for (int ia = odd + 2 * lane; ia < take; ia += 128) {
+            const uint32_t ya = temper(mt[pos + ia]);
+            if (ia + 1 < take) {
+                const uint32_t a = ya >> 5, b = temper(mt[pos + ia + 1]) >> 6;
+                out[(produced + ia) >> 1] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+            } else {
+                carry_word = ya;  // its partner is word 0 of the next block
+            }
+        }
+        __syncthreads();
+        pos += take;
+        produced += take;
+    }
+    if (w_end == total_words && final_state && k * words_per_stream < total_words) {
+        for (int i = lane; i < kN; i += 64) final_state[i] = mt[i];
+        if (lane == 0) final_state[kN] = (uint32_t)pos;
+    }
+}
+
+}  // namespace
+
+extern "C" int n2v_mt19937_jump_host(const uint32_t* key_host, int64_t stride_words, int32_t n_streams,
+                                     uint32_t* states_host) {
+    if (!key_host || !states_host || n_streams < 1 || stride_words < 0)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_host: bad argument");
+    build_modulus();
+    if (!g_mt.ready) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_host: minimal polynomial not found");
+    std::memcpy(states_host, key_host, sizeof(uint32_t) * kN);
+    if (n_streams == 1) return N2V_OK;
+    static std::mutex cache_mu;
+    static uint64_t cached_n = ~0ULL;
+    static Poly cached_g;
+    Poly g;
+    {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        if (cached_n != (uint64_t)stride_words) {
+            cached_g = powmod_x((uint64_t)stride_words);
+            cached_n = (uint64_t)stride_words;
+        }
+        g = cached_g;
+    }
+    for (int k = 1; k < n_streams; ++k)
+        apply_poly(g, states_host + (size_t)(k - 1) * kN, states_host + (size_t)k * kN);
+    return N2V_OK;
+}
+
+extern "C" int n2v_mt19937_fill(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
+                                int64_t n_doubles, double* out, uint32_t* final_state, void* stream) {
+    if (!states || n_streams < 1 || pos < 0 || pos > kN || words_per_stream < 2 || (words_per_stream & 1) ||
+        n_doubles < 0 || (int64_t)n_streams * words_per_stream < 2 * n_doubles)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_fill: bad argument (streams %d, pos %d, stride %lld, n %lld)",
+                         (int)n_streams, (int)pos, (long long)words_per_stream, (long long)n_doubles);
+    if (n_doubles == 0) return N2V_OK;
+    if (!out) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_fill: null output");
+    hipLaunchKernelGGL(mt_fill_kernel, dim3((unsigned)n_streams), dim3(64), 0, (hipStream_t)stream, states, (int)pos,
+                       words_per_stream, 2 * n_doubles, out, final_state);
+    return n2v::check_launch("n2v_mt19937_fill");
+}

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from n2v_hip import csr as _csr
+from n2v_hip import mt19937 as _mt
 from n2v_hip.engine import WalkEngine
 
 
@@ -304,6 +305,13 @@ class Graph():
             raise ValueError("rng must be 'numpy' or 'philox'")
         return self._simulate_numpy_stream(starts, n, num_walks, L)
 
+    def _global_uniforms(self, n, device):
+        """The next n doubles of numpy's global MT19937 stream as a device tensor: generated on
+        the GPU by jump-ahead (default) or by numpy on the host (`host_rng = True`)."""
+        if getattr(self, "host_rng", False):
+            return torch.from_numpy(np.random.random_sample(n)).to(device)
+        return _mt.global_uniforms_device(n, device)
+
     def _simulate_numpy_stream(self, starts, n, num_walks, L):
         """Parity mode.  Walk w = it*n + pos owns the uniforms the sequential reference
         loop would have handed it: offset 2 * sum_{w' < w} (len(w') - 1)."""
@@ -332,14 +340,14 @@ class Graph():
             it = 0
             while it < num_walks:
                 k = min(rounds_per_chunk, num_walks - it)
-                U = torch.from_numpy(np.random.random_sample(per * k)).to(d)
+                U = self._global_uniforms(per * k, d)
                 off = uoff[:n * k].contiguous() if k > 1 else uoff_round
                 self._walk(starts, k, L, rng="uniforms", uniforms=U, walk_uoff=off, round_begin=it,
                          out=(walks[it * n:(it + k) * n], lens[it * n:(it + k) * n]))
                 it += k
             return walks, lens
         state = np.random.get_state()
-        U = torch.from_numpy(np.random.random_sample(total_full)).to(d)
+        U = self._global_uniforms(total_full, d)
         walks, lens = self._walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
         # offsets depend on the lengths of all earlier walks: iterate to the fixed point
         # (each pass makes at least the first not-yet-final walk final)
@@ -352,6 +360,5 @@ class Graph():
             walks, lens = self._walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
         used = int(((lens.to(torch.int64) - 1) * 2).sum().item())
         np.random.set_state(state)
-        if used:
-            np.random.random_sample(used)  # leave the global stream where the reference would
+        _mt.advance_global_state(used // 2)  # leave the global stream where the reference would
         return walks, lens

@@ -299,3 +299,35 @@ def test_on_the_fly_zero_weight_raises(n2v):
     g = n2v.Graph(G, False, 0.5, 2)
     with pytest.raises(ZeroDivisionError):
         g.simulate_walks_on_the_fly(1, 5)
+
+
+def test_device_mt19937_equals_numpy_stream(n2v):
+    """np.random.random_sample(n) regenerated on the device from numpy's global state: same
+    doubles bit for bit, same final global state, from every kind of starting position."""
+    import torch
+    from n2v_hip import mt19937
+    cases = [(123, 0, 10), (123, 0, 1000003), (7, 1001, 312 * 40 + 5), (5, 623, 2_500_001), (9, 1, 1), (9, 0, 311),
+             (11, 624 * 3, 624 * 50)]
+    for seed, pre_words, n in cases:
+        np.random.seed(seed)
+        if pre_words:
+            np.random.randint(0, 2**32, size=pre_words, dtype=np.uint32)   # leaves an arbitrary (odd) position
+        st0 = np.random.get_state()
+        want = np.random.random_sample(n)
+        st_want = np.random.get_state()
+        np.random.set_state(st0)
+        got = mt19937.global_uniforms_device(n, "cuda:0")
+        st_got = np.random.get_state()
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64)), (seed, pre_words, n)
+        assert st_got[2] == st_want[2] and np.array_equal(st_got[1], st_want[1]), (seed, pre_words, n)
+        # one stream (no jump) gives the same result
+        np.random.set_state(st0)
+        got1 = mt19937.global_uniforms_device(n, "cuda:0", n_streams=1)
+        assert torch.equal(got, got1)
+    # host-side generation stays available and identical
+    z = load_case("karate_p025_q4")
+    g = n2v.Graph(_nx_graph(z), False, 0.25, 4.0)
+    g.preprocess_transition_probs()
+    g.host_rng = True
+    np.random.seed(123)
+    assert g.simulate_walks(10, 80) == golden_walks(z, 0)
