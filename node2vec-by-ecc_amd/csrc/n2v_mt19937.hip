@@ -191,32 +191,56 @@ __device__ __forceinline__ uint32_t temper(uint32_t y) {
     return y;
 }
 
+__device__ __forceinline__ void lds_order() {  // one wave per workgroup: LDS is in order, pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// new value of word i of the block twist, from the (partly updated) window in LDS
+__device__ __forceinline__ uint32_t twist_word(const uint32_t* mt, int i) {
+    int i1 = i + 1;
+    if (i1 == kN) i1 = 0;
+    int im = i + kM;
+    if (im >= kN) im -= kN;
+    const uint32_t y = (mt[i] & kUpper) | (mt[i1] & kLower);
+    return mt[im] ^ (y >> 1) ^ ((y & 1u) ? kMatrixA : 0u);
+}
+
 __global__ void __launch_bounds__(64)
 mt_fill_kernel(const uint32_t* __restrict__ states, int pos0, int64_t words_per_stream, int64_t total_words,
                double* __restrict__ out, uint32_t* __restrict__ final_state) {
-    __shared__ uint32_t mt[kN];
+    __shared__ uint32_t mt[kN + 16];
     __shared__ uint32_t carry_word;
     const int lane = threadIdx.x;
     const int64_t k = blockIdx.x;
     for (int i = lane; i < kN; i += 64) mt[i] = states[k * kN + i];
-    __syncthreads();
+    lds_order();
     int pos = pos0;
     int64_t produced = k * words_per_stream;
     const int64_t w_end = min(total_words, produced + words_per_stream);
     while (produced < w_end) {
         if (pos >= kN) {
-            // numpy's block twist, in place, 64 consecutive words at a time (every word a chunk
-            // needs from a later index is still old, everything from an earlier index is new)
-            for (int c = 0; c < kN; c += 64) {
-                const int i = c + lane;
+            // numpy's block twist, in place.  Word i needs old i, i+1 and (i < 227 ? old i+397
+            // : NEW i-227).  64-word chunks c, c+1, c+2 never read each other's outputs
+            // (227 > 3*64), so three chunks share one LDS round trip: all reads, then all writes.
+#pragma unroll
+            for (int c = 0; c < 576; c += 192) {
+                const uint32_t v0 = twist_word(mt, c + lane);
+                const uint32_t v1 = twist_word(mt, c + 64 + lane);
+                const uint32_t v2 = twist_word(mt, c + 128 + lane);
+                lds_order();
+                mt[c + lane] = v0;
+                mt[c + 64 + lane] = v1;
+                mt[c + 128 + lane] = v2;
+                lds_order();
+            }
+            {
                 uint32_t v = 0;
-                if (i < kN) {
-                    const uint32_t y = (mt[i] & kUpper) | (mt[(i + 1) % kN] & kLower);
-                    v = mt[(i + kM) % kN] ^ (y >> 1) ^ ((y & 1u) ? kMatrixA : 0u);
-                }
-                __syncthreads();
-                if (i < kN) mt[i] = v;
-                __syncthreads();
+                if (lane < kN - 576) v = twist_word(mt, 576 + lane);
+                lds_order();
+                if (lane < kN - 576) mt[576 + lane] = v;
+                lds_order();
             }
             pos = 0;
         }
@@ -236,7 +260,7 @@ mt_fill_kernel(const uint32_t* __restrict__ states, int pos0, int64_t words_per_
                 carry_word = ya;  // its partner is word 0 of the next block
             }
         }
-        __syncthreads();
+        lds_order();
         pos += take;
         produced += take;
     }

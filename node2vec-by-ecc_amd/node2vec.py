@@ -360,5 +360,5 @@ class Graph():
             walks, lens = self._walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
         used = int(((lens.to(torch.int64) - 1) * 2).sum().item())
         np.random.set_state(state)
-        _mt.advance_global_state(used // 2)  # leave the global stream where the reference would
+        _mt.advance_global_state(used)  # leave the global stream where the reference would
         return walks, lens
