@@ -5,6 +5,11 @@ There is no CPU fallback: if the HIP library is missing or a call fails, this ra
 import ctypes as C
 import os
 
+# torch first: it ships its own libamdhip64; loading ours before torch's would put a second,
+# device-less HIP runtime into the process (kernel launches then fail with "no ROCm-capable
+# device").  With torch loaded first the library binds to the runtime torch initialised.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libn2v_hip.so")
 

@@ -331,3 +331,36 @@ def test_device_mt19937_equals_numpy_stream(n2v):
     g.host_rng = True
     np.random.seed(123)
     assert g.simulate_walks(10, 80) == golden_walks(z, 0)
+
+
+def test_degenerate_graphs(n2v):
+    """Empty graph, a single self-loop, isolated nodes inside an undirected graph, zero rounds."""
+    import networkx as nx
+    from n2v_hip import csr
+    g = n2v.Graph(nx.Graph(), False, 1, 1)
+    g.preprocess_transition_probs()
+    assert g.simulate_walks(3, 10) == [] and len(g.alias_nodes) == 0 and len(g.alias_edges) == 0
+    G = nx.Graph()
+    G.add_edge(7, 7, weight=2.5)
+    g = n2v.Graph(G, False, 0.5, 2.0)
+    g.preprocess_transition_probs()
+    np.random.seed(0)
+    assert g.simulate_walks(2, 5) == [[7] * 5, [7] * 5]
+    J, q = g.alias_edges[(7, 7)]
+    assert J.tolist() == [0] and q.tolist() == [1.0]
+    # isolated nodes (degree 0) among connected ones: their walks are [node] and take no draws
+    full = csr.CsrGraph(np.arange(8), np.array([0, 2, 4, 6, 6, 6, 7, 8, 8]), np.array([1, 2, 0, 2, 0, 1, 6, 5], dtype=np.int32), None, np.array([3, 0, 7, 1, 2, 4, 5, 6]), False)
+    g = n2v.Graph.from_csr(full, 0.5, 2.0, rng="numpy")
+    g.preprocess_transition_probs()
+    np.random.seed(4)
+    walks = g.simulate_walks(2, 6).tolist()
+    from oracle import c_oracle
+    co = c_oracle.CsrOracle(full.row_ptr, full.col, None, 0.5, 2.0)
+    co.preprocess()
+    ow, ol, nd = co.walk(full.start_order, 2, 6, mode="mt", seed=4)
+    assert walks == walks_from_padded(ow, ol, full.labels)
+    assert [w for w in walks if len(w) == 1] == [[3], [7], [4], [3], [7], [4]]
+    chk = np.random.RandomState(4)
+    chk.random_sample(nd)
+    assert np.random.random_sample() == chk.random_sample()
+    assert g.simulate_walks(0, 6) == [] and len(g.simulate_walks(0, 6)) == 0
