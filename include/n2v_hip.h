@@ -208,6 +208,10 @@ int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bi
 #define N2V_SGNS_PLAIN 0
 #define N2V_SGNS_AGENT 1
 #define N2V_SGNS_ATOMIC 2
+/* OR-ed into update_mode (opt-in, not gensim's sampling scheme): draw the negatives once per
+ * centre word and share them among its context pairs; target rows stay in registers for the
+ * whole window (negative <= 7). */
+#define N2V_SGNS_SHARE_NEGATIVES 4
 int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
                    float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
                    int32_t window, int32_t negative, const uint32_t* sample_int,

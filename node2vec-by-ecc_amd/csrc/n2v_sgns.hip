@@ -371,6 +371,132 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
     if (a.pair_count && lane == 0 && pairs_done) atomicAdd(a.pair_count, pairs_done);
 }
 
+// Opt-in variant (N2V_SGNS_SHARE_NEGATIVES): the `negative` draws are made once per CENTRE word
+// and shared by all of its context pairs (the scheme of Ji et al., "Parallelizing Word2Vec in
+// Shared and Distributed Memory", 2016) instead of once per pair as gensim does.  The target
+// rows then stay in registers for the whole window and are written back once per centre, so a
+// pair touches memory only for its context row: ~0.8 KB instead of 3.1 KB of atomic traffic.
+// Same update rule per (pair, target); different (correlated) negative samples.  negative <= 7.
+template <int VPL, int MODE>
+__global__ void __launch_bounds__(256) sgns_shared_kernel(SgnsArgs a) {
+    extern __shared__ int32_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t* sent = smem + wv * a.lpad;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int my_k = bitrev3(lane & 7);
+    unsigned long long pairs_done = 0;
+
+    for (int64_t wi = (int64_t)blockIdx.x * 4 + wv; wi < a.n_walks; wi += n_waves) {
+        const int len = a.lens ? a.lens[wi] : a.walk_stride;
+        const uint64_t wid = a.walk_id_base + (uint64_t)wi;
+        int n_eff = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int pos = base + lane;
+            bool keep = false;
+            int32_t tok = -1;
+            if (pos < len) {
+                tok = a.walks[wi * a.walk_stride + pos];
+                keep = tok >= 0;
+                if (keep && a.sample_int) keep = !(a.sample_int[tok] < hash32(a.seed, wid, (uint32_t)pos, 0x5AB));
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) sent[n_eff + __popcll(m & ((1ULL << lane) - 1ULL))] = tok;
+            n_eff += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t pushed = a.sent_base + (wi / a.alpha_batch) * a.alpha_batch * a.sent_step;
+        float alpha = a.alpha0 - (a.alpha0 - a.min_alpha) * (float)((double)pushed / (double)a.sent_total);
+        alpha = fmaxf(alpha, a.min_alpha);
+        uint64_t lcg = mix64(a.seed ^ mix64(wid + 0x632BE59BD9B4E019ULL)) & kLcgMask;
+
+        for (int i = 0; i < n_eff; ++i) {
+            const int32_t ci = __builtin_amdgcn_readfirstlane(sent[i]);
+            const int rb = (int)(hash32(a.seed, wid, (uint32_t)i, 0xB17) % (uint32_t)a.window);
+            const int lo = max(0, i - a.window + rb), hi = min(n_eff, i + a.window + 1 - rb);
+            if (hi - lo <= 1) continue;
+            // targets of this centre: slot 0 = the centre itself, slots 1..negative = one draw each
+            int32_t my_t = -1;
+            if (lane >= 1 && lane <= a.negative) {
+                uint64_t s = lcg;
+                for (int d = 1; d < lane; ++d) s = (s * kLcgA + kLcgC) & kLcgMask;
+                my_t = draw_target(a.cum_table, a.lut, a.lut_shift, (uint32_t)((s >> 16) % 2147483647ULL));
+                if (my_t == ci) my_t = -1;
+            }
+            for (int d = 0; d < a.negative; ++d) lcg = (lcg * kLcgA + kLcgC) & kLcgMask;
+            int32_t tgt[8];
+            Row<VPL> n[8], dn[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                tgt[k] = (k == 0) ? ci : __builtin_amdgcn_readlane(my_t, k);
+                // a target drawn twice is trained once (its second copy would race with the first)
+#pragma unroll
+                for (int k2 = 1; k2 < k; ++k2)
+                    if (tgt[k] >= 0 && tgt[k] == tgt[k2]) tgt[k] = -1;
+                if (tgt[k] >= 0) n[k] = load_row<VPL, MODE>(a.syn1neg, tgt[k], a.row_stride, lane);
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    if (tgt[k] < 0) n[k].v[v] = 0.f;
+                    dn[k].v[v] = 0.f;
+                }
+            }
+            for (int j = lo; j < hi; ++j) {
+                if (j == i) continue;
+                const int32_t xj = __builtin_amdgcn_readfirstlane(sent[j]);
+                Row<VPL> h = load_row<VPL, MODE>(a.syn0, xj, a.row_stride, lane);
+                float p[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) acc = fmaf(h.v[v], n[k].v[v], acc);
+                    p[k] = acc;
+                }
+                const float f = reduce8(p, lane);
+                float g = 0.f;
+                if (f > -kMaxExp && f < kMaxExp) {
+                    const float sig = c_exp_table[(int)((f + kMaxExp) * (float)(kExpTableSize / (int)kMaxExp / 2))];
+                    g = ((my_k == 0 ? 1.f : 0.f) - sig) * alpha;
+                }
+                Row<VPL> work;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) work.v[v] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (tgt[k] < 0) continue;
+                    const float gk = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), bitrev3(k)));
+                    if (gk == 0.f) continue;
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) {
+                        work.v[v] = fmaf(gk, n[k].v[v], work.v[v]);
+                        const float d = gk * h.v[v];
+                        n[k].v[v] += d;
+                        dn[k].v[v] += d;
+                    }
+                }
+                if constexpr (MODE == kAtomic) {
+                    add_row<VPL>(a.syn0, xj, a.row_stride, lane, work);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) h.v[v] += work.v[v];
+                    store_row<VPL, MODE>(a.syn0, xj, a.row_stride, lane, h);
+                }
+                ++pairs_done;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (tgt[k] < 0) continue;
+                if constexpr (MODE == kAtomic) add_row<VPL>(a.syn1neg, tgt[k], a.row_stride, lane, dn[k]);
+                else store_row<VPL, MODE>(a.syn1neg, tgt[k], a.row_stride, lane, n[k]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (a.pair_count && lane == 0 && pairs_done) atomicAdd(a.pair_count, pairs_done);
+}
+
 // syn0 ~ U(-0.5/d, 0.5/d), syn1neg = 0 (gensim reset_weights); one Philox call per 4 floats,
 // keyed by the seed and counted by (row, column block) so a row does not depend on n_words.
 __global__ void __launch_bounds__(256)
@@ -472,8 +598,11 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: row_stride %d must be a multiple of 64 in [dim, 512]",
                          (int)row_stride);
     if (lut_bits < 1 || lut_bits > 24) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: lut_bits %d", (int)lut_bits);
+    const bool share = (update_mode & N2V_SGNS_SHARE_NEGATIVES) != 0;
+    update_mode &= ~N2V_SGNS_SHARE_NEGATIVES;
     if (update_mode < kPlain || update_mode > kAtomic)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: update_mode %d", (int)update_mode);
+    if (share && negative > 7) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: shared negatives need negative <= 7");
     if (sentences_total < 1 || alpha_batch < 1 || sentences_step < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad schedule");
     hipStream_t st = (hipStream_t)stream;
     fill_exp_table();
@@ -502,7 +631,8 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);
 #define N2V_SGNS_LAUNCH_M(V, M)                                                            \
-    if (negative <= 5) hipLaunchKernelGGL((sgns_kernel<V, 6, M>), grid, block, shmem, st, a); \
+    if (share) hipLaunchKernelGGL((sgns_shared_kernel<V, M>), grid, block, shmem, st, a);     \
+    else if (negative <= 5) hipLaunchKernelGGL((sgns_kernel<V, 6, M>), grid, block, shmem, st, a); \
     else hipLaunchKernelGGL((sgns_kernel<V, 8, M>), grid, block, shmem, st, a)
 #define N2V_SGNS_LAUNCH(V)                                   \
     if (update_mode == kPlain) { N2V_SGNS_LAUNCH_M(V, kPlain); }        \

@@ -65,7 +65,7 @@ class SgnsModel:
     """Embedding tables + vocabulary statistics of one training run, on one device."""
 
     def __init__(self, n_words, dim=128, window=10, negative=5, alpha=0.025, min_alpha=1e-4, sample=1e-3,
-                 seed=1, device=None, update_mode="atomic"):
+                 seed=1, device=None, update_mode="atomic", share_negatives=False):
         if not torch.cuda.is_available():
             raise RuntimeError("n2v_hip: no GPU visible; the SGNS trainer has no CPU fallback")
         self.lib = _lib.load()
@@ -74,7 +74,7 @@ class SgnsModel:
         self.stride = _row_stride(self.dim)
         self.window, self.negative = int(window), int(negative)
         self.alpha, self.min_alpha, self.sample, self.seed = float(alpha), float(min_alpha), sample, int(seed)
-        self.update_mode = UPDATE_MODES[update_mode]
+        self.update_mode = UPDATE_MODES[update_mode] | (4 if share_negatives else 0)  # N2V_SGNS_SHARE_NEGATIVES
         d = self.device
         self.syn0 = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
         self.syn1neg = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)

@@ -28,7 +28,7 @@ def main():
     modes = os.environ.get("MODES", "plain,agent,atomic").split(",")
     for mode, blocks in [(mo, int(x)) for mo in modes for x in (sys.argv[1:] or [1, 16, 256, 2048])]:
         for seed in (1, 2):
-            m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=seed, update_mode=mode)
+            m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=seed, update_mode=mode.split("+")[0], share_negatives=mode.endswith("+share"))
             m.build_vocab(corpus.walks)
             t = time.perf_counter()
             m.train_pass(corpus.walks, corpus.lens, 0, n, 0, max_blocks=blocks)

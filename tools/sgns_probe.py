@@ -26,7 +26,7 @@ def main():
     torch.cuda.synchronize()
     print(name, "walks", tuple(corpus.walks.shape), flush=True)
     for mode in os.environ.get("MODES", "plain,agent,atomic").split(","):
-        m = sgns.SgnsModel(cg.n_nodes, dim=dim, window=10, negative=5, seed=1, update_mode=mode)
+        m = sgns.SgnsModel(cg.n_nodes, dim=dim, window=10, negative=5, seed=1, update_mode=mode.split("+")[0], share_negatives=mode.endswith("+share"))
         m.build_vocab(corpus.walks)
         for rep in range(2):
             m.pair_count.zero_()
