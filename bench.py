@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--syncs", default="auto", help="replica merges per SGNS pass when N > 1 (auto: staleness bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shared-negatives", action="store_true", help="skip the extra opt-in SGNS variant pass")
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     args = ap.parse_args()
 
@@ -234,6 +235,22 @@ def main():
     t_total, t_walk, t_sgns = [float(x) for x in stats.tolist()]
     steps_all, pairs_all = [float(x) for x in sums.tolist()]
 
+    # opt-in variant, reported separately: negatives shared per centre word (one pass, N=1 only)
+    shared = None
+    if world == 1 and not args.no_shared_negatives:
+        ms = sgns.SgnsModel(N, dim=args.dim, window=window, negative=negative, seed=1, device=dev, share_negatives=True)
+        ms.build_vocab(counts=counts)
+        sgns.train(ms, walks[: max(1, n_local // 10)], lens[: max(1, n_local // 10)], epochs=1)   # warm-up
+        ms.pair_count.zero_()
+        s0, s1 = ev(), ev()
+        s0.record()
+        sgns.train(ms, walks, lens, epochs=1)
+        s1.record()
+        torch.cuda.synchronize()
+        shared = {"metric": "SGNS pair-updates/s, negatives shared per centre word (opt-in; not gensim's sampling)",
+                  "value": ms.pairs_trained() / (s0.elapsed_time(s1) / 1e3), "unit": "pair-updates/s",
+                  "seconds": s0.elapsed_time(s1) / 1e3}
+        del ms
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -271,7 +288,9 @@ def main():
                    if world > 1 else "single GPU", **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
                  "pairs_per_step_global": pairs_all / K, "seconds_per_step": t_sgns / K},
-        "walk": {"steps_per_step_global": steps_all / K, "seconds_per_step": t_walk / K},
+        "walk": {"steps_per_step_global": steps_all / K, "seconds_per_step": t_walk / K,
+                 "table_layout": "fat (32-B slots)" if eng.edge_fat is not None else "thin (16-B slots + records)"},
+        "sgns_shared_negatives": shared,
         "preprocess_seconds": t_pre, "alias_slots": eng.total_slots,
         # dominant kernel by time: sgns_kernel
         "roofline": {"kernel": "sgns_kernel", "bound": "hbm", "achieved": sgns_bytes_launch / sgns_launch_s / 1e9,

@@ -76,8 +76,10 @@ def test_single_pair_update_matches_numpy(torch_cuda):
     torch = torch_cuda
     from n2v_hip import sgns
     d = torch.device("cuda:0")
-    for dim, mode in [(d_, m_) for d_ in (128, 64, 100, 256, 512) for m_ in ("atomic", "agent", "plain")]:
-        m = sgns.SgnsModel(5, dim=dim, window=1, negative=0, sample=0, seed=3, update_mode=mode)
+    for dim, mode, share in [(d_, m_, s_) for d_ in (128, 64, 100, 256, 512) for m_ in ("atomic", "agent", "plain")
+                             for s_ in (False, True)]:
+        m = sgns.SgnsModel(5, dim=dim, window=1, negative=0, sample=0, seed=3, update_mode=mode,
+                           share_negatives=share)
         # non-zero syn1neg so that both tables move
         m.syn1neg[:, :dim] = (torch.rand((5, dim), device=d) - 0.5) * 0.2
         walks = torch.tensor([[1, 3]], dtype=torch.int32, device=d)
@@ -198,6 +200,14 @@ def test_link_prediction_auc_within_band_of_cpu_comparator(torch_cuda):
     assert abs(m.pairs_trained() - pairs_cpu) / pairs_cpu < 0.01
     assert auc_cpu > 0.85
     assert abs(auc_gpu - auc_cpu) <= AUC_BAND, (auc_gpu, auc_cpu)
+    # opt-in variant: negatives drawn once per centre word and shared by its pairs
+    ms = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1, share_negatives=True)
+    ms.build_vocab(corpus.walks)
+    sgns.train(ms, corpus.walks, corpus.lens, epochs=1)
+    auc_sh, _ = linkpred.get_roc_score(ms.vectors(), te_d, neg_d)
+    print("shared negatives: AUC %.5f pairs %d" % (auc_sh, ms.pairs_trained()))
+    assert ms.pairs_trained() == m.pairs_trained()
+    assert abs(auc_sh - auc_cpu) <= AUC_BAND, (auc_sh, auc_cpu)
 
 
 def test_learn_embeddings_dropin_surface(torch_cuda, tmp_path):
