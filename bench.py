@@ -284,7 +284,7 @@ def main():
         "config": {"workload": desc, "walk_length": L, "rounds_per_gpu_per_step": args.rounds,
                    "walks_per_step_global": n_global, "window": window, "negative": negative, "dim": args.dim,
                    "rng": "philox4x32-10 in-kernel (walk rule bit-identical to the reference under given uniforms)",
-                   "sharding": "start-vertex shards, %d delta merges (RCCL all-reduce of both tables) per SGNS pass" % syncs
+                   "sharding": "start-vertex shards, %d 'hot'-weighted merges (RCCL all-reduce of both tables) per SGNS pass" % syncs
                    if world > 1 else "single GPU", **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
                  "pairs_per_step_global": pairs_all / K, "seconds_per_step": t_sgns / K},

@@ -155,30 +155,57 @@ def shard_bounds(n_items, world, rank):
     return b, min(b + per, n_items)
 
 
-def merge_replicas(tables, bases, comm, mode="delta"):
-    """Combine the replicas' tables in place at a sync point.
-    mode 'delta' (default): base + sum of every replica's change since the last sync — what one
-                 shared Hogwild table would have received; `bases` holds the last merged copy.
-                 Faithful to the sequential algorithm as long as the interval between syncs is
-                 short (see auto_syncs); with long intervals the summed changes overshoot.
-    mode 'avg' : mean of the replicas (local SGD); `bases` entries may be None."""
-    for t, b in zip(tables, bases):
+def merge_replicas(tables, bases, comm, mode="hot", weights=None):
+    """Combine the replicas' tables in place at a sync point; `bases` holds the last merged copy.
+    mode 'hot' (default): base + w_row * (sum of every replica's change), w_row in [1/world, 1]
+                 from merge_weights(): rows that receive few updates per interval get the SUM of
+                 the changes (what one shared Hogwild table would have received), rows that every
+                 replica hammers (hubs, frequent negatives) get their MEAN — summing those
+                 overshoots by a factor `world`, averaging cold rows under-trains them by it.
+    mode 'delta': w_row = 1 (pure sum).   mode 'avg': w_row = 1/world (local SGD)."""
+    for i, (t, b) in enumerate(zip(tables, bases)):
         comm.all_reduce_sum(t)
         if mode == "avg":
             t.div_(comm.world)
         elif mode == "delta":
             t.sub_(b, alpha=comm.world - 1)
+        elif mode == "hot":
+            t.sub_(b, alpha=comm.world).mul_(weights[i][:, None]).add_(b)
         else:
             raise ValueError("merge mode %r" % (mode,))
         if b is not None:
             b.copy_(t)
 
 
-# Staleness bound of the 'delta' merge, measured on one MI355X by training G simulated replicas
-# (tools/replica_auc_probe.py, 3000-node graph, CPU comparator AUC 0.8961): with
-# (G-1) * tokens per vocabulary row per interval at about 22 (G=8, 256 syncs) or 12 (G=2, 64
-# syncs) the AUC stays within 0.0005 of the sequential result; at 50 (G=2, 16 syncs) it is off
-# by 0.0023 and at 87 (G=8, 64 syncs) training diverges.
+HOT_BUDGET = 128.0  # updates per replica and interval above which a row is merged towards the mean
+
+
+def merge_weights(counts, interval_tokens_global, world, window, negative, device, budget=HOT_BUDGET):
+    """Per-row merge weights (w_syn0, w_syn1neg) of mode 'hot'.  Expected updates of row v per
+    interval: syn0 (context rows) ~ pairs_per_token * T * p_v; syn1neg (targets) ~
+    pairs_per_token * T * (p_v + negative * p_neg_v), T = tokens of all replicas per interval,
+    p the unigram and p_neg the unigram^0.75 distribution.  With u = (world-1)/world * updates,
+    lambda = min(1, budget / u) and w = lambda + (1 - lambda) / world."""
+    c = torch.as_tensor(counts, dtype=torch.float64, device=device)
+    pv = c / c.sum().clamp_min(1)
+    pn = c ** 0.75
+    pn = pn / pn.sum().clamp_min(1e-300)
+    ppt = window + 0.5
+    out = []
+    for upd in (ppt * interval_tokens_global * pv, ppt * interval_tokens_global * (pv + negative * pn)):
+        u = (world - 1) / world * upd
+        lam = torch.clamp(budget / u.clamp_min(1e-30), max=1.0)
+        out.append((lam + (1 - lam) / world).to(torch.float32))
+    return out
+
+
+# Sync cadence.  Measured on one MI355X by training G simulated replicas
+# (tools/replica_auc_probe.py): on a 3000-node uniform graph (CPU comparator AUC 0.8961) the pure
+# sum ('delta') stays within 0.0005 while (G-1) * tokens per vocabulary row per interval is about
+# 12-22, is off by 0.0023 at 50 and diverges at 87.  On a 20k-node graph WITH hubs (comparator
+# 0.8672) no cadence rescues the pure sum (+0.006 at G=2, +0.020 at G=8: hub rows overshoot) nor
+# the mean (-0.014 / -0.050: cold rows under-train); the 'hot' interpolation at this cadence gives
+# +0.001 / +0.001 (uniform) and about -0.002 / -0.003 (hubs) for G = 2 / 8.
 STALENESS_BUDGET = 12.0
 
 
@@ -196,7 +223,7 @@ def chunk_plan(n_local, n_chunks):
 
 
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
-          merge="delta"):
+          merge="hot"):
     """Train `epochs` passes over this rank's walks.  With a communicator the replicas are
     merged `syncs_per_epoch` times per pass ("auto": auto_syncs), the last one at its end."""
     n_local = int(walks.shape[0])
@@ -207,10 +234,14 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
     bases = None
     n_chunks = 1
     if world > 1:
-        bases = [model.syn0.clone(), model.syn1neg.clone()] if merge == "delta" else [None, None]
+        bases = [model.syn0.clone(), model.syn1neg.clone()] if merge != "avg" else [None, None]
         n_chunks = (auto_syncs(n_walks_global * int(walks.shape[1]), model.n_words, world)
                     if syncs_per_epoch == "auto" else int(syncs_per_epoch))
     plan = chunk_plan(n_local, n_chunks)
+    weights = None
+    if world > 1 and merge == "hot":
+        weights = merge_weights(model.counts, n_walks_global * int(walks.shape[1]) / len(plan), world,
+                                model.window, model.negative, model.device)
     for ep in range(epochs):
         for b, e in plan:
             if e > b:
@@ -219,7 +250,7 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
                                  sentences_base=ep * n_walks_global + b * world, sentences_step=world,
                                  sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b)
             if world > 1:
-                merge_replicas([model.syn0, model.syn1neg], bases, comm, merge)
+                merge_replicas([model.syn0, model.syn1neg], bases, comm, merge, weights)
     return model
 
 
@@ -238,7 +269,7 @@ class _SimulatedComm:
         self._i += 1
 
 
-def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="delta", epochs=1):
+def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="hot", epochs=1):
     """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens,
     shard_offset)` what rank r would hold.  Runs the same schedule and the same merge_replicas
     arithmetic as `train`, interval by interval, so the multi-GPU scheme can be scored for AUC
@@ -247,8 +278,12 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
     L = int(shards[0][0].shape[1])
     n_chunks = (auto_syncs(n_walks_global * L, models[0].n_words, G) if syncs_per_epoch == "auto"
                 else int(syncs_per_epoch))
-    bases = [[m.syn0.clone(), m.syn1neg.clone()] if merge == "delta" else [None, None] for m in models]
+    bases = [[m.syn0.clone(), m.syn1neg.clone()] if merge != "avg" else [None, None] for m in models]
     plans = [chunk_plan(int(w.shape[0]), n_chunks) for w, _, _ in shards]
+    weights = None
+    if merge == "hot":
+        weights = merge_weights(models[0].counts, n_walks_global * L / len(plans[0]), G, models[0].window,
+                                models[0].negative, models[0].device)
     total = epochs * n_walks_global
     for ep in range(epochs):
         for c in range(len(plans[0])):
@@ -261,7 +296,7 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
                                  walk_id_base=ep * n_walks_global + off + b)
             snaps = [[m.syn0.clone() for m in models], [m.syn1neg.clone() for m in models]]
             for r, m in enumerate(models):
-                merge_replicas([m.syn0, m.syn1neg], bases[r], _SimulatedComm(G, snaps), merge)
+                merge_replicas([m.syn0, m.syn1neg], bases[r], _SimulatedComm(G, snaps), merge, weights)
     return n_chunks
 
 

@@ -51,6 +51,17 @@ def test_auto_syncs_and_chunk_plan():
     assert len(chunk_plan(5, 100)) == 5 and chunk_plan(0, 4) == [(0, 0)]
 
 
+def test_merge_weights_limits():
+    from n2v_hip.sgns import merge_weights
+    counts = np.array([10**7, 10**3, 1, 0])
+    w0, w1 = merge_weights(counts, interval_tokens_global=10**6, world=8, window=10, negative=5, device="cpu")
+    assert abs(float(w0[0]) - 1 / 8) < 0.01 and abs(float(w1[0]) - 1 / 8) < 0.01      # hub: mean
+    assert float(w0[2]) == 1.0 and float(w0[3]) == 1.0                               # cold rows: sum
+    assert (w1 <= w0 + 1e-7).all()                                                   # targets are hotter
+    w0, w1 = merge_weights(counts, 10**6, world=1, window=10, negative=5, device="cpu")
+    assert (w0 == 1).all() and (w1 == 1).all()
+
+
 def test_simulated_comm_equals_sum():
     from n2v_hip.sgns import _SimulatedComm, merge_replicas
     base = torch.arange(6, dtype=torch.float32).reshape(2, 3)
@@ -91,18 +102,21 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int
 rank = dist.get_rank()
 comm = sgns._ProcessGroupComm()
 assert comm.world == 2
-for mode in ("avg", "delta"):
+for mode in ("avg", "delta", "hot"):
     base0 = torch.arange(12, dtype=torch.float32).reshape(3, 4)
     t = base0.clone()
     bases = [base0.clone()]
     t[rank] += 1.0 + rank            # each replica changes its own row ...
     t[2] += 10.0 * (rank + 1)        # ... and both change row 2
-    sgns.merge_replicas([t], bases if mode != "avg" else [None], comm, mode)
+    w = [torch.tensor([1.0, 1.0, 0.5])]           # rows 0/1 cold (sum), row 2 hot (mean of 2 replicas)
+    sgns.merge_replicas([t], bases if mode != "avg" else [None], comm, mode, w)
     want = base0.clone()
     if mode == "avg":
         want[0] += 0.5; want[1] += 1.0; want[2] += 15.0
-    else:
+    elif mode == "delta":
         want[0] += 1.0; want[1] += 2.0; want[2] += 30.0
+    else:
+        want[0] += 1.0; want[1] += 2.0; want[2] += 15.0
     assert torch.allclose(t, want), (mode, t, want)
     if mode != "avg":
         assert torch.equal(bases[0], t)

@@ -39,7 +39,19 @@ def simulate(G, corpus, n_nodes, rounds, merge, syncs, mode="atomic"):
                              walk_id_base=off + b)
         for ti, name in enumerate(("syn0", "syn1neg")):
             stack = torch.stack([getattr(m, name) for m in models])
-            if merge == "avg":
+            if merge.startswith("hot"):
+                # per-row interpolation between sum (cold rows) and mean (hot rows) by the expected
+                # number of updates the row receives per replica and interval
+                B = float(merge[3:] or 16)
+                T = n_global * 80.0 / syncs
+                pv = counts.double() / counts.sum()
+                pn = counts.double() ** 0.75
+                pn = pn / pn.sum()
+                U = 10.5 * T * (pv if ti == 0 else (pv + 5 * pn))
+                lam = torch.clamp(B / ((G - 1) * U / G).clamp_min(1e-30), max=1.0).float()
+                w = lam + (1 - lam) / G
+                new = bases[ti] + (stack - bases[ti][None]).sum(0) * w[:, None]
+            elif merge == "avg":
                 new = stack.mean(0)
             elif merge == "delta":
                 new = bases[ti] + (stack - bases[ti][None]).sum(0)
@@ -53,9 +65,48 @@ def simulate(G, corpus, n_nodes, rounds, merge, syncs, mode="atomic"):
     return models[0]
 
 
+def _hub_partition(n=20000, k=100, m_in=200000, m_out=40000, seed=0):
+    """Degree-corrected planted partition: communities + Pareto node activity (hubs)."""
+    rs = np.random.RandomState(seed)
+    comm = rs.randint(0, k, n)
+    theta = rs.pareto(1.5, n) + 1.0
+    order = np.argsort(comm, kind="stable")
+    starts = np.searchsorted(comm[order], np.arange(k + 1))
+    src, dst = [], []
+    per = m_in // k
+    for c in range(k):
+        members = order[starts[c]:starts[c + 1]]
+        if len(members) < 2:
+            continue
+        pr = theta[members] / theta[members].sum()
+        src.append(rs.choice(members, per, p=pr))
+        dst.append(rs.choice(members, per, p=pr))
+    pr = theta / theta.sum()
+    src.append(rs.choice(n, m_out, p=pr))
+    dst.append(rs.choice(n, m_out, p=pr))
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    key = np.minimum(src, dst) * n + np.maximum(src, dst)
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    return np.stack([src[first], dst[first]], 1)
+
+
 def setup(kind):
     if kind == "pp":
         return _auc_setup()
+    if kind == "hub":
+        from n2v_hip import csr
+        from oracle import sgns_oracle
+        edges = _hub_partition()
+        tr, te = sgns_oracle.split_edges(edges)
+        g = csr.from_edges(tr[:, 0], tr[:, 1], None, False)
+        print("hub graph: nodes %d train edges %d max degree %d" % (g.n_nodes, len(tr), g.degrees.max()), flush=True)
+        ing = set(g.labels.tolist())
+        te = np.array([e for e in te.tolist() if e[0] in ing and e[1] in ing])
+        neg = np.array(sgns_oracle.build_neg_samples(g.labels.tolist(), edges.tolist(), seed=0))
+        return g, te, neg
     from n2v_hip import csr, synth
     from oracle import sgns_oracle
     n = int(kind.split(":")[1]) if ":" in kind else 20000
@@ -91,10 +142,14 @@ def main():
         print("CPU comparator threads=%d: AUC %.5f AP %.5f (%.0fs)" % (thr, auc, ap, time.time() - t), flush=True)
     m = simulate(1, corpus, g.n_nodes, rounds, "avg", 1)
     print("G=1: AUC %.5f" % linkpred.get_roc_score(m.vectors(), te_d, neg_d)[0], flush=True)
+    auto = {G: sgns.auto_syncs(corpus.walks.shape[0] * 80, g.n_nodes, G) for G in (2, 8)}
+    print("auto syncs:", auto, flush=True)
     sync_list = [int(x) for x in os.environ.get("SYNCS", "4,16,64").split(",")]
     for G in (2, 8):
         for merge in os.environ.get("MERGES", "sparse_avg,avg,delta").split(","):
             for syncs in sync_list:
+                if syncs <= 0:
+                    syncs = max(1, auto[G] // (-syncs if syncs < 0 else 1))   # 0: auto, -k: auto/k
                 m = simulate(G, corpus, g.n_nodes, rounds, merge, syncs)
                 auc, ap = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
                 print("G=%d merge=%-10s syncs=%3d: AUC %.5f AP %.5f" % (G, merge, syncs, auc, ap), flush=True)
