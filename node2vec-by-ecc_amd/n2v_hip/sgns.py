@@ -177,7 +177,7 @@ def merge_replicas(tables, bases, comm, mode="hot", weights=None):
             b.copy_(t)
 
 
-HOT_BUDGET = 128.0  # updates per replica and interval above which a row is merged towards the mean
+HOT_BUDGET = 256.0  # updates per replica and interval above which a row is merged towards the mean
 
 
 def merge_weights(counts, interval_tokens_global, world, window, negative, device, budget=HOT_BUDGET):
@@ -206,7 +206,7 @@ def merge_weights(counts, interval_tokens_global, world, window, negative, devic
 # 0.8672) no cadence rescues the pure sum (+0.006 at G=2, +0.020 at G=8: hub rows overshoot) nor
 # the mean (-0.014 / -0.050: cold rows under-train); the 'hot' interpolation at this cadence gives
 # +0.001 / +0.001 (uniform) and about -0.002 / -0.003 (hubs) for G = 2 / 8.
-STALENESS_BUDGET = 12.0
+STALENESS_BUDGET = 24.0
 
 
 def auto_syncs(tokens_global, n_words, world):
