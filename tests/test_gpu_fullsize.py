@@ -1,0 +1,163 @@
+"""Full-size property tests (run with -m gpu): BASELINE.json's C2 and C3 graphs are too large for
+the oracle, so the HIP path is held to size-independent properties of the domain instead:
+
+* alias tables: the distribution a table encodes, P(k) = (q_k + sum_{j: J_j = k} (1 - q_j)) / K,
+  equals the normalised p,q-biased weights the reference defines (src/node2vec.py:133-152);
+* walks: every step follows an edge, every walk starts at its start vertex in list(G.nodes())
+  order and has full length on an undirected graph, identical output for both table layouts,
+  for the same seed, and when sharded by start vertex / round;
+* first-order walks (p = q = 1) visit nodes in proportion to their degree;
+* SGNS: the pair count the window rule implies, finite tables, untouched padding."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _is_edge(torch, row_ptr, col, u, v):
+    """Vectorised membership of (u -> v) in a sorted CSR, on the device."""
+    lo = row_ptr[u]
+    hi = row_ptr[u + 1]
+    n_iter = int(torch.log2((hi - lo).max().float().clamp_min(1)).ceil().item()) + 1
+    for _ in range(n_iter):
+        mid = (lo + hi) // 2
+        go = (mid < hi) & (col[mid.clamp_max(col.numel() - 1)] < v)
+        lo = torch.where(go, mid + 1, lo)
+        hi = torch.where(go, hi, mid)
+    ok = lo < row_ptr[u + 1]
+    return ok & (col[lo.clamp_max(col.numel() - 1)] == v)
+
+
+def _check_walks(torch, eng, walks, lens, starts, rounds):
+    n, L = starts.numel(), walks.shape[1]
+    assert walks.shape[0] == n * rounds
+    assert torch.equal(walks[:, 0], starts.repeat(rounds))
+    assert bool((lens == L).all())          # undirected: no dead ends
+    for t in range(0, L - 1, 7):            # every 7th transition of every walk
+        u, v = walks[:, t].long(), walks[:, t + 1].long()
+        assert bool(_is_edge(torch, eng.row_ptr, eng.col.long(), u, v).all()), t
+
+
+def _table_distribution_error(torch, eng, e_idx):
+    """max |P_table(k) - u_k/norm| over the tables of the given CSR entries (unweighted graph)."""
+    p, q = eng.p, eng.q
+    worst = 0.0
+    off = eng.edge_off
+    col = eng.col.long()
+    for chunk in torch.split(e_idx, 20000):
+        src = torch.searchsorted(eng.row_ptr, chunk, right=True) - 1
+        dst = col[chunk]
+        K = eng.deg[dst]
+        tbl = torch.repeat_interleave(torch.arange(chunk.numel(), device=chunk.device), K)
+        first = torch.cumsum(K, 0) - K
+        k = torch.arange(tbl.numel(), device=chunk.device) - first[tbl]
+        slot = off[chunk][tbl] + k
+        qv = eng.slots_q(eng.edge_slots)[slot].clamp(max=1.0)   # `rand() < q` always holds for q >= 1
+        Jv = eng.slots_J(eng.edge_slots)[slot].long()
+        Kf = K[tbl].double()
+        prob = qv.clone()
+        prob.index_add_(0, first[tbl] + Jv, 1.0 - qv)
+        prob = prob / Kf
+        nbr = col[eng.row_ptr[dst][tbl] + k]
+        s = src[tbl]
+        u = torch.where(nbr == s, torch.full_like(qv, 1.0 / p),
+                        torch.where(_is_edge(torch, eng.row_ptr, col, nbr, s), torch.ones_like(qv),
+                                    torch.full_like(qv, 1.0 / q)))
+        norm = torch.zeros(chunk.numel(), dtype=torch.float64, device=chunk.device).index_add_(0, tbl, u)
+        worst = max(worst, float((prob - u / norm[tbl]).abs().max().item()))
+    return worst
+
+
+def test_c2_second_order_properties(torch_cuda):
+    """C2's graph (ER 100k / 1M) with p=0.25, q=4: 4.2e7 alias slots, 1e6 walks."""
+    torch = torch_cuda
+    import node2vec
+    from n2v_hip import synth
+    cg, info = synth.make_config_graph("C2")
+    assert info["nodes"] == 100000 and info["edges"] == 1000000 and info["sum_deg2"] == 41994592
+    g = node2vec.Graph.from_csr(cg, 0.25, 4.0, rng="philox", seed=11)
+    g.preprocess_transition_probs()
+    eng = g._engine
+    assert eng.total_slots == info["sum_deg2"] and eng.edge_fat is not None
+    e_idx = torch.arange(0, cg.nnz, 13, device=eng.device)
+    assert _table_distribution_error(torch, eng, e_idx) < 1e-12
+    a_w, a_l = eng.walk(eng.start_order, 10, 80, rng="philox", seed=11, layout="fat")
+    b_w, b_l = eng.walk(eng.start_order, 10, 80, rng="philox", seed=11, layout="thin")
+    assert torch.equal(a_w, b_w) and torch.equal(a_l, b_l)
+    _check_walks(torch, eng, a_w, a_l, eng.start_order, 10)
+    c_w, _ = eng.walk(eng.start_order, 10, 80, rng="philox", seed=12)
+    assert not torch.equal(a_w, c_w)
+    # sharding: 3 uneven start-vertex shards x rounds in two blocks reproduce the same rows
+    n = cg.n_nodes
+    for (pb, pc) in ((0, 33333), (33333, 50000), (83333, n - 83333)):
+        for (rb, rc) in ((0, 4), (4, 6)):
+            s_w, _ = eng.walk(eng.start_order, rc, 80, rng="philox", seed=11, pos_begin=pb, pos_count=pc, round_begin=rb)
+            want = a_w.view(10, n, 80)[rb:rb + rc, pb:pb + pc].reshape(-1, 80)
+            assert torch.equal(s_w, want)
+
+
+def test_c2_first_order_visits_follow_degree(torch_cuda):
+    """p = q = 1: the walk is the simple random walk, whose stationary distribution is degree / 2E."""
+    torch = torch_cuda
+    import node2vec
+    from n2v_hip import synth
+    cg, _ = synth.make_config_graph("C2")
+    g = node2vec.Graph.from_csr(cg, 1.0, 1.0, rng="philox", seed=5)
+    g.preprocess_transition_probs()
+    eng = g._engine
+    assert eng.first_order
+    w, l = eng.walk(eng.start_order, 10, 80, rng="philox", seed=5)
+    _check_walks(torch, eng, w, l, eng.start_order, 10)
+    visits = torch.bincount(w[:, 40:].reshape(-1).long(), minlength=cg.n_nodes).double()
+    deg = eng.deg.double()
+    expect = deg / deg.sum() * visits.sum()
+    # per-degree-class totals agree within 1 %, overall correlation is near 1
+    for d in (10, 20, 30):
+        m = eng.deg == d
+        assert abs(float(visits[m].sum() / expect[m].sum()) - 1.0) < 0.01, d
+    assert float(torch.corrcoef(torch.stack([visits, expect]))[0, 1]) > 0.95
+
+
+def test_c3_full_size_properties(torch_cuda):
+    """BASELINE C3: power-law 1M nodes / 10M edges, p=0.25 q=4, 1.83e9 alias slots."""
+    torch = torch_cuda
+    import node2vec
+    from n2v_hip import sgns, synth
+    cg, info = synth.make_config_graph("C3")
+    assert info["nodes"] == 1000000 and info["max_deg"] > 5000
+    g = node2vec.Graph.from_csr(cg, 0.25, 4.0, rng="philox", seed=3)
+    g.preprocess_transition_probs()
+    eng = g._engine
+    assert eng.total_slots == info["sum_deg2"]
+    # tables of 40k random CSR entries plus the 2000 entries that lead into the biggest hubs
+    rs = np.random.RandomState(0)
+    pick = torch.from_numpy(rs.randint(0, cg.nnz, 40000)).to(eng.device)
+    hubs = torch.argsort(eng.deg[eng.col.long()], descending=True)[:2000:40]
+    assert _table_distribution_error(torch, eng, torch.cat([pick, hubs])) < 1e-11
+    a_w, a_l = eng.walk(eng.start_order, 2, 80, rng="philox", seed=3, layout="fat")
+    b_w, b_l = eng.walk(eng.start_order, 2, 80, rng="philox", seed=3, layout="thin")
+    assert torch.equal(a_w, b_w) and torch.equal(a_l, b_l)
+    _check_walks(torch, eng, a_w, a_l, eng.start_order, 2)
+    # the on-the-fly kernel agrees on a sample of start vertices (hubs included)
+    sub = torch.cat([eng.start_order[:20000], torch.argsort(eng.deg, descending=True)[:64].int()]).contiguous()
+    t_w, t_l = eng.walk(sub, 1, 40, rng="philox", seed=8)
+    o_w, o_l = eng.walk_on_the_fly(sub, 1, 40, rng="philox", seed=8)
+    assert torch.equal(t_w, o_w) and torch.equal(t_l, o_l)
+    # SGNS over the 2M walks: pair count of the window rule, finite tables, clean padding columns
+    m = sgns.SgnsModel(cg.n_nodes, dim=100, window=10, negative=5, seed=1)   # dim 100: stride 128, 28 padding columns
+    m.build_vocab(a_w)
+    assert int(m.counts.sum()) == a_w.numel()
+    sgns.train(m, a_w, a_l, epochs=1)
+    torch.cuda.synchronize()
+    per_walk = m.pairs_trained() / a_w.shape[0]
+    assert 780 < per_walk < 840, per_walk       # 836 minus what sub-sampling of the hubs removes
+    assert bool(torch.isfinite(m.syn0).all()) and bool(torch.isfinite(m.syn1neg).all())
+    assert bool((m.syn0[:, 100:] == 0).all()) and bool((m.syn1neg[:, 100:] == 0).all())
+    assert float(m.syn0.abs().max()) < 20.0
