@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=10, help="walks per start vertex per step and per GPU (BASELINE: 10)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--syncs", default="auto", help="replica merges per SGNS pass when N > 1 (auto: staleness bound)")
+    ap.add_argument("--update-mode", default="auto", choices=["auto", "atomic", "agent", "plain"],
+                    help="how racing wavefronts share embedding rows (DESIGN.md 4.3); auto = agent above 131072 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shared-negatives", action="store_true", help="skip the extra opt-in SGNS variant pass")
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
@@ -187,7 +189,8 @@ def main():
         counts += torch.bincount(flat[flat >= 0].long(), minlength=N)
     if world > 1:
         comm.all_reduce_sum(counts)
-    model = sgns.SgnsModel(N, dim=args.dim, window=window, negative=negative, seed=1, device=dev)
+    model = sgns.SgnsModel(N, dim=args.dim, window=window, negative=negative, seed=1, device=dev,
+                           update_mode=args.update_mode)
     model.build_vocab(counts=counts)
     shard_offset = pos_begin * rounds_total
     syncs = (sgns.auto_syncs(n_global * L, N, world) if args.syncs == "auto" else int(args.syncs))
@@ -287,6 +290,7 @@ def main():
                    "sharding": "start-vertex shards, %d 'hot'-weighted merges (RCCL all-reduce of both tables) per SGNS pass" % syncs
                    if world > 1 else "single GPU", **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
+                 "row_sharing": model.update_mode_name,
                  "pairs_per_step_global": pairs_all / K, "seconds_per_step": t_sgns / K},
         "walk": {"steps_per_step_global": steps_all / K, "seconds_per_step": t_walk / K,
                  "table_layout": "fat (32-B slots)" if eng.edge_fat is not None else "thin (16-B slots + records)"},

@@ -73,7 +73,7 @@ def learn_embeddings(walks, **overrides):
     model = _sgns.SgnsModel(len(corpus.labels), dim=dim, window=window, negative=overrides.get("negative", 5),
                             alpha=overrides.get("alpha", 0.025), min_alpha=overrides.get("min_alpha", 1e-4),
                             sample=overrides.get("sample", 1e-3), seed=seed, device=corpus.walks.device,
-                            update_mode=overrides.get("update_mode", "atomic"),
+                            update_mode=overrides.get("update_mode", "auto"),
                             share_negatives=overrides.get("share_negatives", False))
     model.build_vocab(corpus.walks)
     _sgns.train(model, corpus.walks, corpus.lens, epochs=epochs)

@@ -19,6 +19,12 @@ import torch
 from . import _lib
 
 UPDATE_MODES = {"plain": 0, "agent": 1, "atomic": 2}  # N2V_SGNS_* of include/n2v_hip.h
+# update_mode="auto": lossless memory-side atomics for small vocabularies, agent-scope
+# load/store above this many rows.  Measured (tools/mode_auc_probe.py, hub-heavy community graphs,
+# link-prediction AUC, two seeds each): 200k nodes atomic 0.87951 / agent 0.87948; 1M nodes atomic
+# 0.87918 / agent 0.88020 — inside the +-0.002 band at 1.6-2.2x the pair rate; at 3000 nodes the
+# agent mode drifts by +0.002 and more (every row is hot), so small tables keep the atomics.
+AUTO_AGENT_MIN_WORDS = 1 << 17
 MAX_WORDS_IN_BATCH = 10000  # gensim: words per job; alpha is stepped once per job
 LUT_BITS = 20
 
@@ -65,7 +71,7 @@ class SgnsModel:
     """Embedding tables + vocabulary statistics of one training run, on one device."""
 
     def __init__(self, n_words, dim=128, window=10, negative=5, alpha=0.025, min_alpha=1e-4, sample=1e-3,
-                 seed=1, device=None, update_mode="atomic", share_negatives=False):
+                 seed=1, device=None, update_mode="auto", share_negatives=False):
         if not torch.cuda.is_available():
             raise RuntimeError("n2v_hip: no GPU visible; the SGNS trainer has no CPU fallback")
         self.lib = _lib.load()
@@ -74,6 +80,9 @@ class SgnsModel:
         self.stride = _row_stride(self.dim)
         self.window, self.negative = int(window), int(negative)
         self.alpha, self.min_alpha, self.sample, self.seed = float(alpha), float(min_alpha), sample, int(seed)
+        if update_mode == "auto":
+            update_mode = "agent" if int(n_words) >= AUTO_AGENT_MIN_WORDS else "atomic"
+        self.update_mode_name = update_mode
         self.update_mode = UPDATE_MODES[update_mode] | (4 if share_negatives else 0)  # N2V_SGNS_SHARE_NEGATIVES
         d = self.device
         self.syn0 = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)

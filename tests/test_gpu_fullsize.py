@@ -161,3 +161,38 @@ def test_c3_full_size_properties(torch_cuda):
     assert bool(torch.isfinite(m.syn0).all()) and bool(torch.isfinite(m.syn1neg).all())
     assert bool((m.syn0[:, 100:] == 0).all()) and bool((m.syn1neg[:, 100:] == 0).all())
     assert float(m.syn0.abs().max()) < 20.0
+
+
+def test_auto_row_sharing_agrees_with_lossless_mode_at_200k(torch_cuda):
+    """update_mode="auto" picks agent-scope load/store above 131072 rows.  On a hub-heavy
+    community graph of 200k nodes its link-prediction AUC must stay within the +-0.002 band of
+    the lossless atomic mode (which the small-graph tests tie to the sequential CPU comparator)."""
+    torch = torch_cuda
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import node2vec
+    from n2v_hip import csr, linkpred, sgns
+    from replica_auc_probe import _hub_partition
+    n = 200000
+    edges = _hub_partition(n=n, k=n // 200, m_in=10 * n, m_out=2 * n, seed=1)
+    tr, te = linkpred.split_edges(edges)
+    full = csr.from_edges(edges[:, 0], edges[:, 1], None, False)
+    g = csr.from_edges(tr[:, 0], tr[:, 1], None, False)
+    if g.n_nodes != full.n_nodes:
+        g = linkpred._with_isolated_nodes(g, full)
+    neg = linkpred.build_neg_samples(full.labels, edges, 0)
+    te_d = np.stack([g.dense_of(te[:, 0]), g.dense_of(te[:, 1])], 1)
+    neg_d = np.stack([g.dense_of(neg[:, 0]), g.dense_of(neg[:, 1])], 1)
+    G = node2vec.Graph.from_csr(g, 1.0, 1.0, rng="philox", seed=1)
+    G.preprocess_transition_probs()
+    corpus = G.simulate_walks(10, 80)
+    aucs = {}
+    for mode in ("auto", "atomic"):
+        m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1, update_mode=mode)
+        m.build_vocab(corpus.walks)
+        sgns.train(m, corpus.walks, corpus.lens, epochs=1)
+        aucs[mode] = linkpred.get_roc_score(m.vectors(), te_d, neg_d)[0]
+        assert m.update_mode_name == ("agent" if mode == "auto" else "atomic")
+    print("AUC auto(agent) %.5f atomic %.5f" % (aucs["auto"], aucs["atomic"]))
+    assert aucs["atomic"] > 0.85 and abs(aucs["auto"] - aucs["atomic"]) <= 0.002
