@@ -44,12 +44,6 @@ inline void window_step(Window& s) {  // A: drop x_k, append x_{k+624}
     s.head = i1;
 }
 
-inline void window_xor(Window& a, const uint32_t* b_logical) {
-    const int first = kN - a.head;  // logical 0..first-1 live at w[head..623], the rest at w[0..head-1]
-    for (int j = 0; j < first; ++j) a.w[a.head + j] ^= b_logical[j];
-    for (int j = first; j < kN; ++j) a.w[j - first] ^= b_logical[j];
-}
-
 // ------------------------------------------------------------------ host: GF(2)[x]
 typedef std::vector<uint64_t> Poly;  // little-endian bits
 
@@ -169,17 +163,26 @@ Poly powmod_x(uint64_t n) {
 }
 
 // out = g(A) in  (Horner); windows as 624 logical words
+// A^i w is words i..i+623 of the sequence x that continues w, so (g(A) w)[j] = XOR over the
+// set bits i of g of x[i + j]: generate x once, then one contiguous 624-word XOR per set bit
+// (vectorises; ~10^4 set bits).
 void apply_poly(const Poly& g, const uint32_t* in, uint32_t* out) {
-    Window h;
-    std::memset(h.w, 0, sizeof(h.w));
-    h.head = 0;
     int deg = kModDeg - 1;
     while (deg > 0 && !pbit(g, deg)) --deg;
-    for (int i = deg; i >= 0; --i) {
-        window_step(h);
-        if (pbit(g, i)) window_xor(h, in);
+    std::vector<uint32_t> x((size_t)deg + kN + 1);
+    std::memcpy(x.data(), in, sizeof(uint32_t) * kN);
+    for (int n = kN; n < deg + kN; ++n) {
+        const uint32_t y = (x[n - kN] & kUpper) | (x[n - kN + 1] & kLower);
+        x[n] = x[n - kN + kM] ^ (y >> 1) ^ ((y & 1u) ? kMatrixA : 0u);
     }
-    for (int j = 0; j < kN; ++j) out[j] = h.w[(h.head + j) % kN];
+    uint32_t acc[kN];
+    std::memset(acc, 0, sizeof(acc));
+    for (int i = 0; i <= deg; ++i) {
+        if (!pbit(g, i)) continue;
+        const uint32_t* xi = x.data() + i;
+        for (int j = 0; j < kN; ++j) acc[j] ^= xi[j];
+    }
+    std::memcpy(out, acc, sizeof(acc));
 }
 
 // ------------------------------------------------------------------ device: one wave per stream
@@ -280,17 +283,25 @@ extern "C" int n2v_mt19937_jump_host(const uint32_t* key_host, int64_t stride_wo
     if (!g_mt.ready) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_host: minimal polynomial not found");
     std::memcpy(states_host, key_host, sizeof(uint32_t) * kN);
     if (n_streams == 1) return N2V_OK;
+    // jump polynomials of the last few strides (a walk alternates between the per-stream stride
+    // and the whole-batch stride that moves numpy's global state)
     static std::mutex cache_mu;
-    static uint64_t cached_n = ~0ULL;
-    static Poly cached_g;
+    static std::vector<std::pair<uint64_t, Poly>> cache;
     Poly g;
     {
         std::lock_guard<std::mutex> lk(cache_mu);
-        if (cached_n != (uint64_t)stride_words) {
-            cached_g = powmod_x((uint64_t)stride_words);
-            cached_n = (uint64_t)stride_words;
+        bool hit = false;
+        for (size_t i = 0; i < cache.size(); ++i)
+            if (cache[i].first == (uint64_t)stride_words) {
+                g = cache[i].second;
+                hit = true;
+                break;
+            }
+        if (!hit) {
+            g = powmod_x((uint64_t)stride_words);
+            if (cache.size() >= 8) cache.erase(cache.begin());
+            cache.emplace_back((uint64_t)stride_words, g);
         }
-        g = cached_g;
     }
     for (int k = 1; k < n_streams; ++k)
         apply_poly(g, states_host + (size_t)(k - 1) * kN, states_host + (size_t)k * kN);

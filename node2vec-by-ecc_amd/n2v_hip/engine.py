@@ -192,45 +192,41 @@ class WalkEngine:
                     _lib.ptr(walks), _lib.ptr(lens), self._stream()))
         return walks, lens
 
-
-def _walk_on_the_fly(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
-                     pos_begin=0, pos_count=None, round_begin=0, out=None):
-    """Launch the on-the-fly walk kernel (no stored edge tables; src/node2vec.py:97-111).
-    Same arguments and results as WalkEngine.walk."""
-    d = self.device
-    L = int(walk_length)
-    if L < 1:
-        raise ValueError("walk_length must be >= 1")
-    if self.p == 0 or self.q == 0:
-        raise ZeroDivisionError("float division by zero")
-    n_starts = int(starts.numel())
-    if pos_count is None:
-        pos_count = n_starts - pos_begin
-    n_local = pos_count * num_rounds
-    with torch.cuda.device(d):
-        if out is None:
-            walks = torch.empty((n_local, L), dtype=torch.int32, device=d)
-            lens = torch.empty(n_local, dtype=torch.int32, device=d)
-        else:
-            walks, lens = out
-        if getattr(self, "_otf_scratch", None) is None and self.max_degree > 512:
-            n_waves = min(256 * 5 * 4, max(4, (n_local + 3) // 4 * 4))
-            self._otf_scratch = torch.empty((n_waves * self.max_degree, 2), dtype=torch.int64, device=d)
-        scratch = getattr(self, "_otf_scratch", None)
-        status = torch.zeros(1, dtype=torch.int32, device=d)
-        mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
-        _lib.check(self.lib.n2v_walk_on_the_fly(
-            _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), self.p, self.q, self.max_degree,
-            _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin, num_rounds, L, mode,
-            _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1), _lib.ptr(scratch),
-            0 if scratch is None else int(scratch.shape[0]), _lib.ptr(walks), _lib.ptr(lens), _lib.ptr(status),
-            self._stream()))
-        if int(status.item()) & _lib.N2V_STATUS_ZERO_NORM:
+    def walk_on_the_fly(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
+                         pos_begin=0, pos_count=None, round_begin=0, out=None):
+        """Launch the on-the-fly walk kernel (no stored edge tables; src/node2vec.py:97-111).
+        Same arguments and results as WalkEngine.walk."""
+        d = self.device
+        L = int(walk_length)
+        if L < 1:
+            raise ValueError("walk_length must be >= 1")
+        if self.p == 0 or self.q == 0:
             raise ZeroDivisionError("float division by zero")
-    return walks, lens
-
-
-WalkEngine.walk_on_the_fly = _walk_on_the_fly
+        n_starts = int(starts.numel())
+        if pos_count is None:
+            pos_count = n_starts - pos_begin
+        n_local = pos_count * num_rounds
+        with torch.cuda.device(d):
+            if out is None:
+                walks = torch.empty((n_local, L), dtype=torch.int32, device=d)
+                lens = torch.empty(n_local, dtype=torch.int32, device=d)
+            else:
+                walks, lens = out
+            if getattr(self, "_otf_scratch", None) is None and self.max_degree > 512:
+                n_waves = min(256 * 5 * 4, max(4, (n_local + 3) // 4 * 4))
+                self._otf_scratch = torch.empty((n_waves * self.max_degree, 2), dtype=torch.int64, device=d)
+            scratch = getattr(self, "_otf_scratch", None)
+            status = torch.zeros(1, dtype=torch.int32, device=d)
+            mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
+            _lib.check(self.lib.n2v_walk_on_the_fly(
+                _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), self.p, self.q, self.max_degree,
+                _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin, num_rounds, L, mode,
+                _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1), _lib.ptr(scratch),
+                0 if scratch is None else int(scratch.shape[0]), _lib.ptr(walks), _lib.ptr(lens), _lib.ptr(status),
+                self._stream()))
+            if int(status.item()) & _lib.N2V_STATUS_ZERO_NORM:
+                raise ZeroDivisionError("float division by zero")
+        return walks, lens
 
 
 def alias_setup_device(prob_tables, device=None):

@@ -320,10 +320,12 @@ def test_device_mt19937_equals_numpy_stream(n2v):
         st_got = np.random.get_state()
         assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64)), (seed, pre_words, n)
         assert st_got[2] == st_want[2] and np.array_equal(st_got[1], st_want[1]), (seed, pre_words, n)
-        # one stream (no jump) gives the same result
+        # one stream (no jump) gives the same result; so does reading the state back from the kernel
         np.random.set_state(st0)
-        got1 = mt19937.global_uniforms_device(n, "cuda:0", n_streams=1)
+        got1 = mt19937.global_uniforms_device(n, "cuda:0", n_streams=1, state_from_device=True)
+        st_dev = np.random.get_state()
         assert torch.equal(got, got1)
+        assert st_dev[2] == st_want[2] and np.array_equal(st_dev[1], st_want[1]), (seed, pre_words, n)
     # host-side generation stays available and identical
     z = load_case("karate_p025_q4")
     g = n2v.Graph(_nx_graph(z), False, 0.25, 4.0)
