@@ -113,44 +113,17 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
-    ndev = torch.cuda.device_count()
-    if ndev == 0:
+    if torch.cuda.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback)")
-    dev = torch.device("cuda:%d" % (local_rank % ndev))
-    torch.cuda.set_device(dev)
-    comm = None
-    host_staged = False
-    if world > 1:
-        import torch.distributed as dist
-        backend = args.backend
-        if backend == "auto":
-            backend = "nccl" if ndev >= world else "gloo"   # gloo = rehearsal on a box with fewer GPUs
-        host_staged = backend == "gloo"
-        dist.init_process_group(backend, init_method="env://", rank=rank, world_size=world,
-                                device_id=None if host_staged else dev)
     import node2vec
+    from n2v_hip import dist as n2v_dist
     from n2v_hip import sgns, synth
-
-    if world > 1:
-        class Comm(sgns._ProcessGroupComm):
-            def all_reduce_sum(self, t):
-                if host_staged:
-                    h = t.cpu()
-                    self.dist.all_reduce(h)
-                    t.copy_(h)
-                else:
-                    self.dist.all_reduce(t)
-        comm = Comm()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+    ctx = n2v_dist.RankContext(backend=args.backend)   # one process per GPU; RCCL unless rehearsing over gloo
+    rank, dev, comm, barrier = ctx.rank, ctx.device, ctx.comm, ctx.barrier
 
     gkey, p, q, desc = CONFIGS[args.config]
     L, window, negative = 80, 10, 5
@@ -183,12 +156,7 @@ def main():
 
     # vocabulary statistics (gensim build_vocab) from one batch of walks, identical on all ranks
     walk_step(-1)
-    counts = torch.zeros(N, dtype=torch.int64, device=dev)
-    for b in range(0, n_local, 1 << 20):   # chunked: keeps the int64 temporaries small
-        flat = walks[b:b + (1 << 20)].reshape(-1)
-        counts += torch.bincount(flat[flat >= 0].long(), minlength=N)
-    if world > 1:
-        comm.all_reduce_sum(counts)
+    counts = n2v_dist.global_counts(walks, N, ctx)
     model = sgns.SgnsModel(N, dim=args.dim, window=window, negative=negative, seed=1, device=dev,
                            update_mode=args.update_mode)
     model.build_vocab(counts=counts)
@@ -227,14 +195,10 @@ def main():
     t_walk = sum(a.elapsed_time(b) for a, b, _, _ in marks) / 1e3
     t_sgns = sum(c.elapsed_time(d) for _, _, c, d in marks) / 1e3
 
-    stats = torch.tensor([t_total, t_walk, t_sgns], dtype=torch.float64, device=dev)
+    stats = ctx.all_reduce_max(torch.tensor([t_total, t_walk, t_sgns], dtype=torch.float64, device=dev))
     sums = torch.tensor([float(steps_done.item()), float(model.pairs_trained())], dtype=torch.float64, device=dev)
     if world > 1:
-        import torch.distributed as dist
-        if host_staged:
-            stats, sums = stats.cpu(), sums.cpu()
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        comm.all_reduce_sum(sums)
     t_total, t_walk, t_sgns = [float(x) for x in stats.tolist()]
     steps_all, pairs_all = [float(x) for x in sums.tolist()]
 
@@ -255,8 +219,7 @@ def main():
                   "seconds": s0.elapsed_time(s1) / 1e3}
         del ms
     if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
+        ctx.close()
         return
     K = args.steps
     walk_rate = steps_all / t_walk
@@ -317,8 +280,7 @@ def main():
                                     model.counts, args.dim))
         log("[bench] cpu baselines took %.1fs" % (time.perf_counter() - t0))
     print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

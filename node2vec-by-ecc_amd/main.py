@@ -8,8 +8,10 @@ pure Python + gensim (src/main.py:66-101).  ``learn_embeddings`` reads the modul
 ``args`` exactly as the reference does (src/main.py:87).
 '''
 import argparse
+import os
 
 import numpy as np
+import torch
 
 import node2vec
 from n2v_hip import csr as _csr
@@ -75,8 +77,21 @@ def learn_embeddings(walks, **overrides):
                             sample=overrides.get("sample", 1e-3), seed=seed, device=corpus.walks.device,
                             update_mode=overrides.get("update_mode", "auto"),
                             share_negatives=overrides.get("share_negatives", False))
-    model.build_vocab(corpus.walks)
-    _sgns.train(model, corpus.walks, corpus.lens, epochs=epochs)
+    ctx = overrides.get("ctx")
+    if ctx is None or ctx.world == 1:
+        model.build_vocab(corpus.walks)
+        _sgns.train(model, corpus.walks, corpus.lens, epochs=epochs)
+    else:
+        # one process per GPU: `walks` is this rank's shard (Graph.simulate_walks_shard); word counts
+        # and the learning-rate schedule are global, the replicas are merged over RCCL
+        from n2v_hip import dist as _dist
+        model.build_vocab(counts=_dist.global_counts(corpus.walks, len(corpus.labels), ctx))
+        n_local = int(corpus.walks.shape[0])
+        tot = torch.tensor([n_local], dtype=torch.int64, device=corpus.walks.device)
+        ctx.comm.all_reduce_sum(tot)
+        b, _ = _sgns.shard_bounds(overrides["n_starts"], ctx.world, ctx.rank)
+        _dist.train_sharded(model, corpus.walks, corpus.lens, ctx, n_walks_global=int(tot.item()),
+                            shard_offset=b * overrides["num_walks"], epochs=epochs)
     wv = _sgns.KeyedVectors(corpus.labels, model.counts, model.vectors().cpu().numpy())
     return _sgns.Word2VecResult(wv, model, model.pairs_trained())
 
@@ -91,14 +106,21 @@ def main(args_):
     G = node2vec.Graph(nx_G, args.directed, args.p, args.q, rng=getattr(args, "rng", "numpy"),
                        seed=getattr(args, "seed", 1))
     G.preprocess_transition_probs()
-    walks = G.simulate_walks(args.num_walks, args.walk_length)
-    emb = learn_embeddings(walks)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        walks = G.simulate_walks(args.num_walks, args.walk_length)
+        return learn_embeddings(walks)
+    # launched by torch.distributed.run, one rank per GPU: walks shard by start vertex, every
+    # rank ends with the same merged embedding (BASELINE config C4)
+    from n2v_hip import dist as _dist
+    ctx = _dist.RankContext()
+    walks = G.simulate_walks_shard(args.num_walks, args.walk_length, ctx.rank, ctx.world)
+    emb = learn_embeddings(walks, ctx=ctx, n_starts=G._csr.n_nodes, num_walks=args.num_walks)
+    ctx.barrier()
     return emb
 
 
 if __name__ == "__main__":
     args = parse_args()
     emb = main(args)
-    import os
-    if args.output and os.path.isdir(os.path.dirname(args.output) or "."):
+    if int(os.environ.get("RANK", "0")) == 0 and args.output and os.path.isdir(os.path.dirname(args.output) or "."):
         emb.wv.save_word2vec_format(args.output)

@@ -305,6 +305,49 @@ class Graph():
             raise ValueError("rng must be 'numpy' or 'philox'")
         return self._simulate_numpy_stream(starts, n, num_walks, L)
 
+    def simulate_walks_shard(self, num_walks, walk_length, rank, world):
+        """The walks one of `world` GPUs owns: all rounds over the rank's
+        contiguous block of start positions (as src/main_link.py:261-264 splits the start nodes).
+        Row r*len(block)+i of the result is row r*N + block_begin + i of simulate_walks(): in
+        Philox mode because the counter is the global walk index, in numpy mode because every
+        rank jumps numpy's global MT19937 stream to the offsets its walks own — and leaves the
+        global state where the full, single-process call would have left it."""
+        if self._engine is None or not self._engine.ready:
+            raise AttributeError("'Graph' object has no attribute 'alias_nodes'")
+        eng = self._engine
+        d = eng.device
+        L = max(int(walk_length), 1)
+        num_walks = int(num_walks)
+        n = int(eng.start_order.numel())
+        per = -(-n // int(world))
+        b = min(int(rank) * per, n)
+        cnt = min(b + per, n) - b
+        if self.rng == "philox":
+            walks, lens = eng.walk(eng.start_order, num_walks, L, rng="philox", seed=self.seed, pos_begin=b, pos_count=cnt)
+            return WalkCorpus(walks, lens, self._csr.labels)
+        if bool(self._csr.directed) and bool((eng.deg == 0).any().item()):
+            raise NotImplementedError("numpy-stream sharding needs walks of known length (no reachable sinks)")
+        active = (eng.deg[eng.start_order.long()] > 0).to(torch.int64) * (2 * (L - 1))
+        prefix = torch.cumsum(active, 0) - active           # uniforms owned by earlier starts of a round
+        per_round = int(active.sum().item())
+        base = int(prefix[b].item()) if cnt else 0
+        seg = int(active[b:b + cnt].sum().item())
+        uoff = (prefix[b:b + cnt] - base).contiguous()
+        walks = torch.empty((cnt * num_walks, L), dtype=torch.int32, device=d)
+        lens = torch.empty(cnt * num_walks, dtype=torch.int32, device=d)
+        st0 = np.random.get_state()
+        for it in range(num_walks):
+            if cnt == 0:
+                break
+            np.random.set_state(st0)
+            _mt.advance_global_state((per_round * it + base))
+            U = self._global_uniforms(max(seg, 2), d)
+            eng.walk(eng.start_order, 1, L, rng="uniforms", uniforms=U, walk_uoff=uoff, pos_begin=b, pos_count=cnt,
+                     round_begin=it, out=(walks[it * cnt:(it + 1) * cnt], lens[it * cnt:(it + 1) * cnt]))
+        np.random.set_state(st0)
+        _mt.advance_global_state(per_round * num_walks)
+        return WalkCorpus(walks, lens, self._csr.labels)
+
     def _global_uniforms(self, n, device):
         """The next n doubles of numpy's global MT19937 stream as a device tensor: generated on
         the GPU by jump-ahead (default) or by numpy on the host (`host_rng = True`)."""

@@ -366,3 +366,37 @@ def test_degenerate_graphs(n2v):
     chk.random_sample(nd)
     assert np.random.random_sample() == chk.random_sample()
     assert g.simulate_walks(0, 6) == [] and len(g.simulate_walks(0, 6)) == 0
+
+
+def test_shards_reproduce_the_single_process_walks(n2v):
+    """Graph.simulate_walks_shard for every rank of a 3-GPU layout, run one after another on this
+    GPU: the union equals simulate_walks row for row — in the reference-exact numpy mode (each
+    shard jumps the global MT19937 stream to the offsets it owns and leaves the global state
+    where the full call would) and in Philox mode."""
+    import torch
+    z = load_case("er600_p05_q2")
+    g = n2v.Graph(_nx_graph(z), False, float(z["p"]), float(z["q"]))
+    g.preprocess_transition_probs()
+    n, r, L = len(z["nodes"]), 3, 25
+    for rng in ("numpy", "philox"):
+        g.rng = rng
+        g.seed = 99
+        np.random.seed(2024)
+        full = g.simulate_walks(r, L)
+        st_full = np.random.get_state()
+        fw = full.walks.view(r, n, L)
+        for world in (3, 8):
+            for rank in range(world):
+                np.random.seed(2024)
+                sh = g.simulate_walks_shard(r, L, rank, world)
+                per = -(-n // world)
+                b, e = min(rank * per, n), min(rank * per + per, n)
+                assert torch.equal(sh.walks.view(r, e - b, L), fw[:, b:e]), (rng, world, rank)
+                if rng == "numpy":
+                    st = np.random.get_state()
+                    assert st[2] == st_full[2] and np.array_equal(st[1], st_full[1])
+    # the golden walks through the sharded path (world = 1)
+    g.rng = "numpy"
+    seed, r, L = z["walk_meta"][0][:3].tolist()
+    np.random.seed(seed)
+    assert g.simulate_walks_shard(r, L, 0, 1) == golden_walks(z, 0)
