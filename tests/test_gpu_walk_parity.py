@@ -400,3 +400,56 @@ def test_shards_reproduce_the_single_process_walks(n2v):
     seed, r, L = z["walk_meta"][0][:3].tolist()
     np.random.seed(seed)
     assert g.simulate_walks_shard(r, L, 0, 1) == golden_walks(z, 0)
+
+
+def test_randomised_parity_sweep(n2v):
+    """40 random small graphs (directed or not, weighted or not, self-loops, isolated targets,
+    duplicate lines, p and q from a grid incl. 1): tables and reference-exact walks vs the C oracle
+    for every graph, vs the pure-Python oracle for every fourth; table-driven (thin and fat) and
+    on-the-fly kernels."""
+    import torch
+    from n2v_hip import csr
+    from oracle import c_oracle
+    from oracle import n2v_oracle as orc
+    rs = np.random.RandomState(77)
+    grid = [0.25, 0.5, 1.0, 2.0, 4.0, 0.3]
+    for trial in range(40):
+        n = int(rs.randint(3, 60))
+        m = int(rs.randint(2, 6 * n))
+        directed, weighted = bool(rs.randint(2)), bool(rs.randint(2))
+        src = rs.randint(0, n, m) * 3 + 1
+        dst = rs.randint(0, n, m) * 3 + 1
+        w = (rs.randint(1, 17, m) / 4.0) if weighted else None
+        p, q = float(grid[rs.randint(6)]), float(grid[rs.randint(6)])
+        cg = csr.from_edges(src, dst, w, directed)
+        g = n2v.Graph.from_csr(cg, p, q, rng="numpy")
+        g.preprocess_transition_probs()
+        eng = g._engine
+        co = c_oracle.CsrOracle(cg.row_ptr, cg.col, cg.w, p, q)
+        co.preprocess(first_order_shortcut=eng.first_order)
+        assert np.array_equal(eng.slots_J(eng.node_slots).cpu().numpy()[:cg.nnz], co.nodeJ), trial
+        assert np.array_equal(_bits(eng.slots_q(eng.node_slots).cpu().numpy()[:cg.nnz]), _bits(co.nodeq)), trial
+        if not eng.first_order:
+            T = int(co.edge_off[-1])
+            assert np.array_equal(eng.slots_J(eng.edge_slots).cpu().numpy()[:T], co.edgeJ), trial
+            assert np.array_equal(_bits(eng.slots_q(eng.edge_slots).cpu().numpy()[:T]), _bits(co.edgeq)), trial
+        r, L = int(rs.randint(1, 4)), int(rs.randint(1, 30))
+        seed = int(rs.randint(1 << 30))
+        ow, ol, nd = co.walk(cg.start_order, r, L, mode="mt", seed=seed)
+        want = walks_from_padded(ow, ol, cg.labels)
+        np.random.seed(seed)
+        got = g.simulate_walks(r, L)
+        assert got == want, (trial, directed, weighted, p, q)
+        chk = np.random.RandomState(seed)
+        chk.random_sample(nd)
+        assert np.random.random_sample() == chk.random_sample(), trial
+        g2 = n2v.Graph.from_csr(cg, p, q, rng="numpy")
+        np.random.seed(seed)
+        assert g2.simulate_walks_on_the_fly(r, L) == want, trial
+        tw, tl = eng.walk(eng.start_order, r, max(L, 1), rng="philox", seed=seed, layout="thin")
+        fw, fl = eng.walk(eng.start_order, r, max(L, 1), rng="philox", seed=seed, layout="fat")
+        assert torch.equal(tw, fw) and torch.equal(tl, fl), trial
+        if trial % 4 == 0:
+            G = orc.OracleGraph(list(zip(src.tolist(), dst.tolist())), None if w is None else w.tolist(), directed)
+            o = orc.Node2VecOracle(G, directed, p, q)
+            assert o.simulate_walks(r, L, seed=seed, on_the_fly=True) == want, trial
