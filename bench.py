@@ -109,6 +109,7 @@ def main():
                     help="how racing wavefronts share embedding rows (DESIGN.md 4.3); auto = agent above 131072 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shared-negatives", action="store_true", help="skip the extra opt-in SGNS variant pass")
+    ap.add_argument("--no-reference-exact", action="store_true", help="skip the extra reference-exact walk pass")
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     args = ap.parse_args()
 
@@ -218,6 +219,23 @@ def main():
                   "value": ms.pairs_trained() / (s0.elapsed_time(s1) / 1e3), "unit": "pair-updates/s",
                   "seconds": s0.elapsed_time(s1) / 1e3}
         del ms
+    # the reference-exact mode, reported separately (N=1): numpy's global MT19937 stream regenerated
+    # on the device, end to end (uniform generation + walk), same walks as the reference for this seed
+    exact = None
+    if world == 1 and not args.no_reference_exact:
+        g.rng = "numpy"
+        np.random.seed(123)
+        g.simulate_walks(1, L)                       # warm-up (jump polynomials, allocator)
+        np.random.seed(123)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        corpus = g.simulate_walks(args.rounds, L)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        exact = {"metric": "walk-steps/s, reference-exact mode (np.random.seed(123) stream, generated on the GPU)",
+                 "value": float((corpus.lens.long() - 1).sum().item()) / dt, "unit": "walk-steps/s", "seconds": dt}
+        del corpus
+        g.rng = "philox"
     if rank != 0:
         ctx.close()
         return
@@ -257,6 +275,7 @@ def main():
                  "pairs_per_step_global": pairs_all / K, "seconds_per_step": t_sgns / K},
         "walk": {"steps_per_step_global": steps_all / K, "seconds_per_step": t_walk / K,
                  "table_layout": "fat (32-B slots)" if eng.edge_fat is not None else "thin (16-B slots + records)"},
+        "walk_reference_exact": exact,
         "sgns_shared_negatives": shared,
         "preprocess_seconds": t_pre, "alias_slots": eng.total_slots,
         # dominant kernel by time: sgns_kernel
