@@ -85,7 +85,9 @@ def build_neg_samples(labels, true_edges, seed=0):
 
 
 def run(edges, p=1.0, q=1.0, num_walks=5, walk_length=40, dimensions=128, window_size=10, iter=1,
-        directed=False, test_ratio=0.5, split_seed=123, neg_seed=0, rng="philox", seed=1, device=None):
+        directed=False, test_ratio=0.5, split_seed=123, neg_seed=0, rng="philox", seed=1, device=None,
+        add_user_edges=False, user_edges_mode="ratio", user_edges_ratio=0.1, user_edges_thre=0.5,
+        unseparated=False):
     """The AUC path of src/main_link.py:519-563 (defaults of src/settings.py: 5 walks of length
     40, d=128): split the edges 50/50, walk and embed on the TRAINING graph only (nodes isolated
     by the removal keep their length-1 walks), score test edges against sampled non-edges of
@@ -110,8 +112,22 @@ def run(edges, p=1.0, q=1.0, num_walks=5, walk_length=40, dimensions=128, window
     te_d = np.stack([train.dense_of(te[:, 0]), train.dense_of(te[:, 1])], 1)
     neg_d = np.stack([train.dense_of(neg[:, 0]), train.dense_of(neg[:, 1])], 1)
     roc, ap = get_roc_score(model.vectors(), te_d, neg_d)
-    return {"roc": roc, "ap": ap, "n_nodes": int(full.n_nodes), "n_train": int(len(tr)), "n_test": int(len(te)),
-            "pairs_trained": model.pairs_trained(), "model": model, "graph": g}
+    out = {"roc": roc, "ap": ap, "n_nodes": int(full.n_nodes), "n_train": int(len(tr)), "n_test": int(len(te)),
+           "pairs_trained": model.pairs_trained(), "model": model, "graph": g, "roc_user": None, "ap_user": None}
+    if add_user_edges:
+        # src/main_link.py:568-599: similarity edges between user nodes, then walk, embed and score again
+        from . import augment
+        train2, n_added = augment.augment_graph(train, model.vectors(), user_edges_mode, user_edges_ratio,
+                                                user_edges_thre, unseparated)
+        g2 = node2vec.Graph.from_csr(train2, p, q, device=device, rng=rng, seed=seed)
+        g2.preprocess_transition_probs()
+        corpus2 = g2.simulate_walks(num_walks, walk_length)
+        model2 = sgns.SgnsModel(train2.n_nodes, dim=dimensions, window=window_size, seed=seed, device=corpus2.walks.device)
+        model2.build_vocab(corpus2.walks)
+        sgns.train(model2, corpus2.walks, corpus2.lens, epochs=iter)
+        out["roc_user"], out["ap_user"] = get_roc_score(model2.vectors(), te_d, neg_d)
+        out.update({"edges_added": n_added, "model_user": model2, "graph_user": g2})
+    return out
 
 
 def _with_isolated_nodes(train, full):

@@ -287,3 +287,34 @@ def test_main_link_flow_end_to_end(torch_cuda):
     assert res["n_train"] + res["n_test"] == len(edges) and abs(res["n_train"] - res["n_test"]) <= 1
     assert 0.8 < res["roc"] <= 1.0 and 0.7 < res["ap"] <= 1.0, (res["roc"], res["ap"])
     print("main_link flow: AUC %.4f AP %.4f" % (res["roc"], res["ap"]))
+
+
+def test_main_link_flow_with_user_edges(torch_cuda):
+    """src/main_link.py:568-599: add similarity edges between user nodes (ids without the
+    '9999999' item prefix), walk + embed on the augmented weighted graph, score again; the
+    device selection equals the oracle's restatement on the embedding it was given."""
+    torch = torch_cuda
+    from n2v_hip import augment, linkpred
+    from oracle import augment_oracle
+    edges = _planted_partition(n=600, k=6, m_in=5000, m_out=800, seed=4)
+    item = edges[:, 1] % 3 == 0                     # a third of the nodes play the item role
+    edges = edges.copy()
+    relabel = lambda x: np.where(x % 3 == 0, 99999990000 + x, x)
+    edges = np.stack([relabel(edges[:, 0]), relabel(edges[:, 1])], 1)
+    res = linkpred.run(edges, num_walks=5, walk_length=40, add_user_edges=True, user_edges_mode="ratio",
+                       user_edges_ratio=0.02)
+    assert res["roc_user"] is not None and 0.5 < res["roc_user"] <= 1.0
+    g = res["graph"]._csr
+    users = augment.user_nodes(g.labels[g.start_order])
+    assert len(users) == int((g.labels < 99999990000).sum()) and res["edges_added"] == len(users) * int(len(users) * 0.02)
+    assert res["graph_user"]._csr.w is not None     # the augmented graph is weighted
+    # device selection == oracle on the same vectors
+    vec = res["model"].vectors()
+    ud = torch.as_tensor(g.dense_of(users).astype(np.int64), device=vec.device)
+    s, d, w = augment.add_edges(vec[ud], "ratio", 0.02, 0.5)
+    emb = {int(u): vec[int(i)].cpu().numpy() for u, i in zip(users, ud.tolist())}
+    want = augment_oracle.add_user_edge([int(u) for u in users], emb, "ratio", 0.02, 0.5)
+    got = list(zip(users[s.cpu().numpy()].tolist(), users[d.cpu().numpy()].tolist()))
+    agree = sum(1 for a, b in zip(got, [(x[0], x[1]) for x in want]) if a == b) / max(len(want), 1)
+    assert len(got) == len(want) and agree > 0.999   # fp32 GEMM vs per-pair dot: only near-ties may swap
+    print("user edges: %d added, AUC %.4f -> %.4f" % (res["edges_added"], res["roc"], res["roc_user"]))
