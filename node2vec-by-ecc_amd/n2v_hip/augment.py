@@ -12,7 +12,7 @@ user in descending order (ties in list order) with weight 1; "step" keeps simila
 with weight 1; "relu" the same with weight = similarity; "relu-ratio" is "relu" with the ratio as
 its threshold (that is what :469 does); "linear" keeps every pair with weight = similarity.
 PARITY UNPINNED: the reference's main_link.py does not import here (pathos, gensim), its output
-is pinned by no fixture; tests compare against oracle/augment_oracle.py, restated from the text.
+is pinned by no fixture; the tests compare against a plain-Python restatement of that text.
 """
 import numpy as np
 import torch
