@@ -14,31 +14,14 @@
 // Compile with -ffp-contract=off: no fused multiply-add may replace the reference's
 // separately rounded operations.
 #include "n2v_common.h"
+#include "n2v_vose.h"
 
 namespace {
 
 // On entry T[k].q holds the normalised probability of slot k (src/node2vec.py:150/187).
+// The pairing itself (register-carried, reference-exact) is in n2v_vose.h.
 __device__ __forceinline__ void vose_inplace(n2v_alias_slot* __restrict__ T, int64_t K) {
-    int64_t ns = 0, nl = 0;
-    const double Kd = (double)K;
-    for (int64_t k = 0; k < K; ++k) {
-        const double qk = Kd * T[k].q;  // q[kk] = K*prob, :253
-        T[k].q = qk;
-        T[k].J = 0;
-        if (qk < 1.0) T[ns++].aux = (int32_t)k;  // smaller.append(kk)
-        else T[K - (++nl)].aux = (int32_t)k;     // larger.append(kk)
-    }
-    while (ns > 0 && nl > 0) {
-        const int32_t small = T[--ns].aux;  // smaller.pop()
-        const int32_t large = T[K - nl].aux;  // larger.pop()
-        --nl;
-        T[small].J = large;
-        double t = T[large].q + T[small].q;  // q[large] + q[small] - 1.0, left to right (:264)
-        t = t - 1.0;
-        T[large].q = t;
-        if (t < 1.0) T[ns++].aux = large;
-        else T[K - (++nl)].aux = large;
-    }
+    n2v::vose_pair<true>(T, K);
 }
 
 __device__ __forceinline__ bool row_contains(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,

@@ -17,6 +17,7 @@
 // scratch row of max_degree slots otherwise.  Serial chains of many waves interleave on a
 // SIMD, so throughput comes from occupancy; -ffp-contract=off keeps every rounding separate.
 #include "n2v_common.h"
+#include "n2v_vose.h"
 
 namespace {
 
@@ -79,22 +80,7 @@ __device__ __forceinline__ double sum_serial(SlotPtr T, int K) {
 
 template <typename SlotPtr>
 __device__ __forceinline__ void pair_serial(SlotPtr T, int K) {
-    int ns = 0, nl = 0;
-    for (int k = 0; k < K; ++k) {  // :252-257 (q[kk] = K*prob already applied by the wave)
-        if (T[k].q < 1.0) T[ns++].aux = k;
-        else T[K - (++nl)].aux = k;
-    }
-    while (ns > 0 && nl > 0) {  // :259-268
-        const int small = T[--ns].aux;
-        const int large = T[K - nl].aux;
-        --nl;
-        T[small].J = large;
-        double t = T[large].q + T[small].q;
-        t = t - 1.0;
-        T[large].q = t;
-        if (t < 1.0) T[ns++].aux = large;
-        else T[K - (++nl)].aux = large;
-    }
+    n2v::vose_pair<false>(T, (int64_t)K);  // :252-268, register-carried (n2v_vose.h)
 }
 
 // one step's table for (prev -> cur); prev < 0 means the first step (node table, :13-25)
