@@ -69,23 +69,26 @@ __device__ __forceinline__ bool row_contains(const int64_t* __restrict__ row_ptr
     return lo < end && col[lo] == v;
 }
 
-// serial pieces, run by one lane: T[k].q holds the unnormalised weights on entry of sum_serial,
-// the probabilities times K on entry of pair_serial
-template <typename SlotPtr>
-__device__ __forceinline__ double sum_serial(SlotPtr T, int K) {
-    double norm = 0.0;
-    for (int k = 0; k < K; ++k) norm = norm + T[k].q;  // sum(), src/node2vec.py:149/:22
-    return norm;
+__device__ __forceinline__ void wave_sync() {  // order this wave's LDS / scratch traffic between phases
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <typename SlotPtr>
-__device__ __forceinline__ void pair_serial(SlotPtr T, int K) {
-    n2v::vose_pair<false>(T, (int64_t)K);  // :252-268, register-carried (n2v_vose.h)
+__device__ __forceinline__ double readlane_f64(double v, int j) {  // j wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
 }
 
-// one step's table for (prev -> cur); prev < 0 means the first step (node table, :13-25)
+// One step's table for (prev -> cur); prev < 0 means the first step (node table, :13-25).
+// The two inherently serial pieces keep the reference's order of operations but are fed
+// cooperatively: 64 slots are loaded by the 64 lanes in one coalesced access and then consumed
+// one after the other through v_readlane, by every lane redundantly (uniform control flow), so the
+// serial chain is two fp64 adds per slot instead of a dependent memory round trip per slot.
 template <typename SlotPtr>
 __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t prev, int64_t base, int K, int lane) {
+    // ---- 1. unnormalised weights, in parallel (:142-148)
     for (int k = lane; k < K; k += 64) {
         const int32_t nb = a.col[base + k];
         const double wt = a.w ? a.w[base + k] : 1.0;
@@ -95,27 +98,82 @@ __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t
         else if (row_contains(a.row_ptr, a.col, nb, prev)) u = wt;
         else u = wt / a.q;
         T[k].q = u;
-        T[k].J = 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
+    // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149 / :22)
     double norm = 0.0;
-    if (lane == 0) norm = sum_serial(T, K);
-    norm = __shfl(norm, 0);
-    if (norm == 0.0) return false;  // ZeroDivisionError in the reference (:150/:23)
-    const double Kd = (double)K;
-    for (int k = lane; k < K; k += 64) {
-        const double prob = T[k].q / norm;  // :150
-        T[k].q = Kd * prob;                 // :253
+    for (int c = 0; c < K; c += 64) {
+        const double v = (c + lane < K) ? T[c + lane].q : 0.0;
+        const int cnt = min(64, K - c);
+        for (int j = 0; j < cnt; ++j) norm = norm + readlane_f64(v, j);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane == 0) pair_serial(T, K);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (norm == 0.0) return false;  // ZeroDivisionError in the reference (:150/:23)
+    // ---- 3. q = K * (u / norm) and the two index stacks, in parallel (:150, :252-257): `smaller`
+    //         grows up from slot 0, `larger` down from slot K-1, both in index order
+    const double Kd = (double)K;
+    int ns = 0, nl = 0;
+    for (int c = 0; c < K; c += 64) {
+        const int k = c + lane;
+        const bool valid = k < K;
+        double qk = 0.0;
+        if (valid) {
+            qk = Kd * (T[k].q / norm);
+            T[k].q = qk;
+            T[k].J = 0;
+        }
+        const bool is_small = valid && (qk < 1.0);
+        const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        if (is_small) T[ns + __popcll(ms & below)].aux = k;
+        else if (valid) T[K - (nl + __popcll(ml & below) + 1)].aux = k;
+        ns += __popcll(ms);
+        nl += __popcll(ml);
+    }
+    wave_sync();
+    // ---- 4. pairing (:259-268).  A pushed element is always the next one popped from its stack, so
+    //         it stays in registers; the memory `smaller` stack is streamed 64 entries at a time.
+    int mem_s = ns, mem_l = nl;
+    bool hasS = false, hasL = false;
+    int rsi = 0, rli = 0;
+    double rsq = 0.0, rlq = 0.0;
+    int ci = 0, c_cnt = 0, c_pos = 0;
+    double cq = 0.0;
+    while ((mem_s > 0 || hasS) && (mem_l > 0 || hasL)) {
+        int small, large;
+        double qs, ql;
+        if (hasS) {
+            small = rsi; qs = rsq; hasS = false;
+            if (lane == 0) T[small].q = qs;
+        } else {
+            if (c_pos == c_cnt) {  // next up-to-64 entries of `smaller`, in pop order, one per lane
+                const int pos = mem_s - 1 - lane;
+                if (pos >= 0) { ci = T[pos].aux; cq = T[ci].q; }
+                c_cnt = min(64, mem_s);
+                c_pos = 0;
+            }
+            small = __builtin_amdgcn_readlane(ci, c_pos);
+            qs = readlane_f64(cq, c_pos);
+            ++c_pos;
+            --mem_s;
+        }
+        if (hasL) {
+            large = rli; ql = rlq; hasL = false;
+        } else {
+            large = T[K - mem_l].aux;
+            --mem_l;
+            ql = T[large].q;
+        }
+        if (lane == 0) T[small].J = large;
+        double t = ql + qs;  // left to right (:264)
+        t = t - 1.0;
+        if (t < 1.0) { hasS = true; rsi = large; rsq = t; }
+        else { hasL = true; rli = large; rlq = t; }
+    }
+    if (lane == 0) {
+        if (hasS) T[rsi].q = rsq;
+        if (hasL) T[rli].q = rlq;
+    }
+    wave_sync();
     return true;
 }
 
