@@ -80,10 +80,11 @@ int n2v_build_node_tables(int64_t n_nodes, const int64_t* row_ptr, const int32_t
  * table of (src -> dst=col[e]) is written to slots[edge_off[e] ...], deg(dst) slots.
  * edge_off: int64[nnz+1], exclusive prefix sum of deg(col[e]).  `src_of`: int32[nnz], the
  * row of each CSR entry.  `order` lets the caller bin tables by size (one lane builds one
- * table, so lanes of a wave should get similar sizes).                                    */
+ * table, so lanes of a wave should get similar sizes).  symmetric != 0 declares the CSR
+ * symmetric (undirected graph): G.has_edge(nbr, src) is then looked up in src's own row.   */
 int n2v_build_edge_tables(int64_t n_nodes, const int64_t* row_ptr, const int32_t* col,
                           const double* w, const int32_t* src_of, double p, double q,
-                          const int64_t* edge_off, const int32_t* order, int64_t e_begin,
+                          int32_t symmetric, const int64_t* edge_off, const int32_t* order, int64_t e_begin,
                           int64_t e_end, n2v_alias_slot* slots, int32_t* status, void* stream);
 
 /* Walk records.  edge_off == NULL: first-order shortcut (p == q == 1), every record
@@ -165,7 +166,7 @@ int n2v_mt19937_fill(const uint32_t* states, int32_t n_streams, int32_t pos, int
  * max_degree > 512; may be NULL otherwise).  status: int32[1], N2V_STATUS_ZERO_NORM on a
  * zero-sum neighbourhood.  Other arguments as n2v_walk.                                   */
 int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
-                        int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+                        int32_t symmetric, int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
                         int64_t pos_count, int64_t round_begin, int64_t round_count,
                         int32_t walk_length, int32_t rng_mode, const double* uniforms,
                         const int64_t* walk_uoff, uint64_t seed, n2v_alias_slot* scratch,

@@ -65,7 +65,7 @@ node_tables_kernel(int64_t n_nodes, const int64_t* __restrict__ row_ptr, const d
 __global__ void __launch_bounds__(256)
 edge_tables_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                    const double* __restrict__ w, const int32_t* __restrict__ src_of, double p, double q,
-                   const int64_t* __restrict__ edge_off, const int32_t* __restrict__ order, int64_t e_begin,
+                   int32_t symmetric, const int64_t* __restrict__ edge_off, const int32_t* __restrict__ order, int64_t e_begin,
                    int64_t e_end, n2v_alias_slot* __restrict__ slots, int32_t* __restrict__ status) {
     const int64_t i = e_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= e_end) return;
@@ -80,7 +80,9 @@ edge_tables_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restric
         const double wt = w ? w[b + k] : 1.0;
         double u;
         if (nb == src) u = wt / p;                               // :143-144
-        else if (row_contains(row_ptr, col, nb, src)) u = wt;    // G.has_edge(dst_nbr, src), :145-146
+        // G.has_edge(dst_nbr, src), :145-146; on an undirected graph that is "dst_nbr in row(src)":
+        // the lane then probes ONE row for all of its slots instead of a different row per slot
+        else if (symmetric ? row_contains(row_ptr, col, src, nb) : row_contains(row_ptr, col, nb, src)) u = wt;
         else u = wt / q;                                         // :147-148
         T[k].q = u;
         norm = norm + u;  // sum(), :149
@@ -117,7 +119,8 @@ extern "C" int n2v_build_node_tables(int64_t n_nodes, const int64_t* row_ptr, co
 }
 
 extern "C" int n2v_build_edge_tables(int64_t n_nodes, const int64_t* row_ptr, const int32_t* col, const double* w,
-                                     const int32_t* src_of, double p, double q, const int64_t* edge_off,
+                                     const int32_t* src_of, double p, double q, int32_t symmetric,
+                                     const int64_t* edge_off,
                                      const int32_t* order, int64_t e_begin, int64_t e_end, n2v_alias_slot* slots,
                                      int32_t* status, void* stream) {
     if (n_nodes < 0 || e_begin < 0 || e_end < e_begin)
@@ -128,8 +131,8 @@ extern "C" int n2v_build_edge_tables(int64_t n_nodes, const int64_t* row_ptr, co
         return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables: null pointer");
     if (!(p == p) || !(q == q)) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables: p or q is NaN");
     hipLaunchKernelGGL(edge_tables_kernel, dim3(n2v::grid_for(e_end - e_begin, 256)), dim3(256), 0,
-                       (hipStream_t)stream, row_ptr, col, w, src_of, p, q, edge_off, order, e_begin, e_end, slots,
-                       status);
+                       (hipStream_t)stream, row_ptr, col, w, src_of, p, q, symmetric, edge_off, order, e_begin, e_end,
+                       slots, status);
     return n2v::check_launch("n2v_build_edge_tables");
 }
 

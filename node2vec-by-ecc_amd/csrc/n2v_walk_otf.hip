@@ -28,6 +28,7 @@ struct OtfArgs {
     const int32_t* col;
     const double* w;
     double p, q;
+    int32_t symmetric;  // undirected graph: has_edge(nbr, prev) == nbr in row(prev), one shared row
     const int32_t* starts;
     int64_t n_starts, pos_begin, pos_count, round_begin, n_local;
     int32_t L;
@@ -95,7 +96,8 @@ __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t
         double u;
         if (prev < 0) u = wt;
         else if (nb == prev) u = wt / a.p;
-        else if (row_contains(a.row_ptr, a.col, nb, prev)) u = wt;
+        else if (a.symmetric ? row_contains(a.row_ptr, a.col, prev, nb)   // every lane probes prev's row
+                             : row_contains(a.row_ptr, a.col, nb, prev)) u = wt;
         else u = wt / a.q;
         T[k].q = u;
     }
@@ -230,7 +232,7 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
 }  // namespace
 
 extern "C" int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
-                                   int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+                                   int32_t symmetric, int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
                                    int64_t pos_count, int64_t round_begin, int64_t round_count, int32_t walk_length,
                                    int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
                                    n2v_alias_slot* scratch, int64_t scratch_slots, int32_t* walks, int32_t* lens,
@@ -258,7 +260,7 @@ extern "C" int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, c
         if (fit < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: scratch smaller than 4 x max_degree slots");
         if (blocks > fit) blocks = fit;
     }
-    OtfArgs a{row_ptr, col, w, p, q, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
+    OtfArgs a{row_ptr, col, w, p, q, symmetric, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
               rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, walks, lens, status};
     hipLaunchKernelGGL(walk_otf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return n2v::check_launch("n2v_walk_on_the_fly");

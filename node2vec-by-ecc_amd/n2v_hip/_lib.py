@@ -25,7 +25,7 @@ SIGNATURES = {
     "n2v_last_error": (C.c_char_p, []),
     "n2v_alias_setup_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr]),
     "n2v_build_node_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "n2v_build_edge_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _f64, _f64, _ptr, _ptr, _i64, _i64,
+    "n2v_build_edge_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _f64, _f64, _i32, _ptr, _ptr, _i64, _i64,
                                         _ptr, _ptr, _ptr]),
     "n2v_build_edge_recs": (C.c_int, [_i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "n2v_walk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr,
@@ -35,7 +35,7 @@ SIGNATURES = {
     "n2v_build_fat_slots": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "n2v_walk_fat": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr, _u64,
                                _ptr, _ptr, _ptr]),
-    "n2v_walk_on_the_fly": (C.c_int, [_ptr, _ptr, _ptr, _f64, _f64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i32,
+    "n2v_walk_on_the_fly": (C.c_int, [_ptr, _ptr, _ptr, _f64, _f64, _i32, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i32,
                                       _i32, _ptr, _ptr, _u64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "n2v_sgns_init": (C.c_int, [_ptr, _ptr, _i64, _i32, _i32, _u64, _ptr]),
     "n2v_build_neg_lut": (C.c_int, [_ptr, _i64, _i32, _ptr, _ptr]),

@@ -85,7 +85,7 @@ class WalkEngine:
                     torch.arange(N, dtype=torch.int32, device=d), self.deg)
                 _lib.check(self.lib.n2v_build_edge_tables(
                     N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
-                    self.p, self.q, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz,
+                    self.p, self.q, 0 if csr.directed else 1, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz,
                     _lib.ptr(self.edge_slots), _lib.ptr(status), self._stream()))
                 del order, src_of, kdst
             _lib.check(self.lib.n2v_build_edge_recs(
@@ -219,7 +219,8 @@ class WalkEngine:
             status = torch.zeros(1, dtype=torch.int32, device=d)
             mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
             _lib.check(self.lib.n2v_walk_on_the_fly(
-                _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), self.p, self.q, self.max_degree,
+                _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), self.p, self.q,
+                0 if self.csr.directed else 1, self.max_degree,
                 _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin, num_rounds, L, mode,
                 _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1), _lib.ptr(scratch),
                 0 if scratch is None else int(scratch.shape[0]), _lib.ptr(walks), _lib.ptr(lens), _lib.ptr(status),
