@@ -226,7 +226,10 @@ __device__ __forceinline__ void add_row(float* base, int64_t row, int stride, in
 template <int VPL, int G, int MODE>
 __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
     extern __shared__ int32_t smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from
+    // it (walk id, loop bounds, table sizes) is scalar and loops branch on SCC instead of EXEC
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int32_t* sent = smem + wv * a.lpad;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     const int my_k = bitrev3(lane & 7);  // which of the 8 reduced values this lane ends up holding
@@ -380,7 +383,10 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
 template <int VPL, int MODE>
 __global__ void __launch_bounds__(256) sgns_shared_kernel(SgnsArgs a) {
     extern __shared__ int32_t smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from
+    // it (walk id, loop bounds, table sizes) is scalar and loops branch on SCC instead of EXEC
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int32_t* sent = smem + wv * a.lpad;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     const int my_k = bitrev3(lane & 7);

@@ -76,6 +76,18 @@ __device__ __forceinline__ void wave_sync() {  // order this wave's LDS / scratc
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Values that are equal in all 64 lanes by construction but reach us through vector loads or
+// vector arithmetic: moving them through v_readfirstlane makes them scalar for the compiler, so
+// the serial loops below branch on SCC and keep their counters in SGPRs instead of running as
+// exec-masked "divergent" loops (which cost ~60 instructions per slot instead of ~15).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+    return ((int64_t)uni((int)(v >> 32)) << 32) | (uint32_t)uni((int)v);
+}
+__device__ __forceinline__ double unid(double v) {
+    return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v)));
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int j) {  // j wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
@@ -109,6 +121,7 @@ __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t
         const int cnt = min(64, K - c);
         for (int j = 0; j < cnt; ++j) norm = norm + readlane_f64(v, j);
     }
+    norm = unid(norm);
     if (norm == 0.0) return false;  // ZeroDivisionError in the reference (:150/:23)
     // ---- 3. q = K * (u / norm) and the two index stacks, in parallel (:150, :252-257): `smaller`
     //         grows up from slot 0, `larger` down from slot K-1, both in index order
@@ -131,6 +144,8 @@ __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t
         ns += __popcll(ms);
         nl += __popcll(ml);
     }
+    ns = uni(ns);
+    nl = uni(nl);
     wave_sync();
     // ---- 4. pairing (:259-268).  A pushed element is always the next one popped from its stack, so
     //         it stays in registers; the memory `smaller` stack is streamed 64 entries at a time.
@@ -161,14 +176,14 @@ __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t
         if (hasL) {
             large = rli; ql = rlq; hasL = false;
         } else {
-            large = T[K - mem_l].aux;
+            large = uni(T[K - mem_l].aux);
             --mem_l;
-            ql = T[large].q;
+            ql = unid(T[large].q);
         }
         if (lane == 0) T[small].J = large;
         double t = ql + qs;  // left to right (:264)
         t = t - 1.0;
-        if (t < 1.0) { hasS = true; rsi = large; rsq = t; }
+        if (uni((int)(t < 1.0))) { hasS = true; rsi = large; rsq = t; }
         else { hasL = true; rli = large; rlq = t; }
     }
     if (lane == 0) {
@@ -181,7 +196,10 @@ __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t
 
 __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
     __shared__ n2v_alias_slot lds[4 * kLdsSlots];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from
+    // it (walk id, loop bounds, table sizes) is scalar and loops branch on SCC instead of EXEC
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     n2v_alias_slot* Tl = lds + wv * kLdsSlots;
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
     n2v_alias_slot* Tg = a.scratch + wave_global * a.max_degree;
@@ -191,7 +209,7 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
     for (int64_t lw = wave_global; lw < a.n_local; lw += n_waves) {
         const int64_t rl = lw / a.pos_count, pl = lw - rl * a.pos_count;
         const uint64_t gw = (uint64_t)((a.round_begin + rl) * a.n_starts + a.pos_begin + pl);
-        int32_t cur = a.starts[a.pos_begin + pl], prev = -1;
+        int32_t cur = uni(a.starts[a.pos_begin + pl]), prev = -1;
         int32_t* out = a.walks + lw * (int64_t)L;
         const double* up = nullptr;
         if (a.rng_mode == N2V_RNG_UNIFORMS)
@@ -200,8 +218,8 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
         int32_t len = 1;
         bool failed = false;
         for (; len < L; ++len) {
-            const int64_t base = a.row_ptr[cur];
-            const int K = (int)(a.row_ptr[cur + 1] - base);
+            const int64_t base = uni64(a.row_ptr[cur]);
+            const int K = uni((int)(a.row_ptr[cur + 1] - base));
             if (K == 0) break;  // dead end (:50-51)
             bool ok;
             if (K <= kLdsSlots) ok = build_table(a, Tl, prev, base, K, lane);
@@ -217,7 +235,7 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
             else { qk = Tg[kk].q; Jk = Tg[kk].J; }
             const int pick = (u2 < qk) ? kk : Jk;  // :278-281
             prev = cur;
-            cur = a.col[base + pick];
+            cur = uni(a.col[base + pick]);
             if (lane == 0) out[len] = cur;
             __builtin_amdgcn_wave_barrier();  // the table is rebuilt in place on the next step
         }
