@@ -21,7 +21,7 @@ namespace {
 // On entry T[k].q holds the normalised probability of slot k (src/node2vec.py:150/187).
 // The pairing itself (register-carried, reference-exact) is in n2v_vose.h.
 __device__ __forceinline__ void vose_inplace(n2v_alias_slot* __restrict__ T, int64_t K) {
-    n2v::vose_pair<true>(T, K);
+    n2v::vose_pair<n2v::kProb>(T, K);
 }
 
 __device__ __forceinline__ bool row_contains(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -58,8 +58,8 @@ node_tables_kernel(int64_t n_nodes, const int64_t* __restrict__ row_ptr, const d
         atomicOr(status, N2V_STATUS_ZERO_NORM);
         return;
     }
-    for (int64_t k = 0; k < K; ++k) T[k].q = (w ? w[b + k] : 1.0) / norm;  // :187
-    vose_inplace(T, K);
+    for (int64_t k = 0; k < K; ++k) T[k].q = (w ? w[b + k] : 1.0);
+    n2v::vose_pair<n2v::kWeight>(T, K, norm);  // prob = u / norm (:187), q = K * prob (:253), pairing
 }
 
 __global__ void __launch_bounds__(256)
@@ -91,8 +91,7 @@ edge_tables_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restric
         atomicOr(status, N2V_STATUS_ZERO_NORM);
         return;
     }
-    for (int64_t k = 0; k < K; ++k) T[k].q = T[k].q / norm;  // :150
-    vose_inplace(T, K);
+    n2v::vose_pair<n2v::kWeight>(T, K, norm);  // prob = u / norm (:150), q = K * prob (:253), pairing
 }
 
 }  // namespace

@@ -19,15 +19,20 @@
 
 namespace n2v {
 
-// SCALE: T[k].q holds the normalised probability on entry and is multiplied by K here (:253);
-// otherwise it already holds K*prob.  SlotPtr: n2v_alias_slot* into global memory or LDS.
-template <bool SCALE, typename SlotPtr>
-__device__ __forceinline__ void vose_pair(SlotPtr T, int64_t K) {
+// What T[k].q holds on entry: kScaled = K*prob already; kProb = the normalised probability, multiplied
+// by K here (:253); kWeight = the unnormalised weight u, turned into K * (u / norm) here (:150 then
+// :253, two roundings as in the reference) so that the caller needs no separate normalising pass.
+// SlotPtr: n2v_alias_slot* into global memory or LDS.
+enum : int { kScaled = 0, kProb = 1, kWeight = 2 };
+
+template <int INPUT, typename SlotPtr>
+__device__ __forceinline__ void vose_pair(SlotPtr T, int64_t K, double norm = 1.0) {
     int64_t ns = 0, nl = 0;
     const double Kd = (double)K;
     for (int64_t k = 0; k < K; ++k) {  // :252-257
         double qk = T[k].q;
-        if (SCALE) {
+        if (INPUT != kScaled) {
+            if (INPUT == kWeight) qk = qk / norm;
             qk = Kd * qk;
             T[k].q = qk;
         }
