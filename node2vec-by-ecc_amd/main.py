@@ -20,34 +20,35 @@ from n2v_hip import sgns as _sgns
 args = None
 
 
+# (flag, type, default, help) of src/main.py:18-64 — same names, same defaults
+_FLAGS = [
+    ("--input", str, "graph/karate.edgelist", "input edgelist"),
+    ("--output", str, "emb/karate.emb", "where the word2vec-text embeddings go"),
+    ("--dimensions", int, 128, "embedding width d"),
+    ("--walk-length", int, 80, "nodes per walk"),
+    ("--num-walks", int, 10, "walks per start node"),
+    ("--window-size", int, 10, "skip-gram window"),
+    ("--iter", int, 1, "SGD epochs"),
+    ("--workers", int, 8, "accepted for compatibility; the GPU replaces gensim's worker threads"),
+    ("--p", float, 1, "return parameter"),
+    ("--q", float, 1, "in-out parameter"),
+]
+_SWITCHES = [("weighted", "unweighted"), ("directed", "undirected")]   # default: the second of each pair
+
+
 def parse_args(argv=None):
-    '''
-    Parses the node2vec arguments (names and defaults of src/main.py:18-64).
-    '''
-    parser = argparse.ArgumentParser(description="Run node2vec.")
-    parser.add_argument('--input', nargs='?', default='graph/karate.edgelist', help='Input graph path')
-    parser.add_argument('--output', nargs='?', default='emb/karate.emb', help='Embeddings path')
-    parser.add_argument('--dimensions', type=int, default=128, help='Number of dimensions. Default is 128.')
-    parser.add_argument('--walk-length', type=int, default=80, help='Length of walk per source. Default is 80.')
-    parser.add_argument('--num-walks', type=int, default=10, help='Number of walks per source. Default is 10.')
-    parser.add_argument('--window-size', type=int, default=10, help='Context size for optimization. Default is 10.')
-    parser.add_argument('--iter', default=1, type=int, help='Number of epochs in SGD')
-    parser.add_argument('--workers', type=int, default=8, help='Accepted for compatibility (the GPU replaces the worker threads).')
-    parser.add_argument('--p', type=float, default=1, help='Return hyperparameter. Default is 1.')
-    parser.add_argument('--q', type=float, default=1, help='Inout hyperparameter. Default is 1.')
-    parser.add_argument('--weighted', dest='weighted', action='store_true',
-                        help='Boolean specifying (un)weighted. Default is unweighted.')
-    parser.add_argument('--unweighted', dest='unweighted', action='store_false')
-    parser.set_defaults(weighted=False)
-    parser.add_argument('--directed', dest='directed', action='store_true',
-                        help='Graph is (un)directed. Default is undirected.')
-    parser.add_argument('--undirected', dest='undirected', action='store_false')
-    parser.set_defaults(directed=False)
-    # extensions (not in the reference): RNG mode of the walk and its seed
-    parser.add_argument('--rng', default='numpy', choices=['numpy', 'philox'],
-                        help="'numpy': consume numpy's global MT19937 stream like the reference; 'philox': in-kernel RNG")
-    parser.add_argument('--seed', type=int, default=1, help='Seed of the philox walk RNG and of the SGNS trainer')
-    return parser.parse_args(argv)
+    """The reference's command line (src/main.py:18-64) plus --rng / --seed."""
+    ap = argparse.ArgumentParser(description="node2vec on MI355X")
+    for flag, typ, default, doc in _FLAGS:
+        ap.add_argument(flag, type=typ, default=default, nargs="?" if typ is str else None, help=doc)
+    for on, off in _SWITCHES:
+        ap.add_argument("--" + on, dest=on, action="store_true")
+        ap.add_argument("--" + off, dest=off, action="store_false")
+        ap.set_defaults(**{on: False})
+    ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"],
+                    help="numpy: consume numpy's global MT19937 stream like the reference; philox: in-kernel RNG")
+    ap.add_argument("--seed", type=int, default=1, help="seed of the philox walk RNG and of the SGNS trainer")
+    return ap.parse_args(argv)
 
 
 def read_graph():
