@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libn2v_hip.so")
+SO_PATH = os.environ.get("N2V_HIP_LIB") or os.path.join(_HERE, "libn2v_hip.so")  # override: A/B builds
 
 N2V_OK = 0
 N2V_STATUS_ZERO_NORM = 1
