@@ -18,8 +18,10 @@ N2V_STATUS_ZERO_NORM = 1
 RNG_UNIFORMS = 0
 RNG_PHILOX = 1
 
-# name -> (restype, argtypes); mirrors include/n2v_hip.h one to one
+# name -> (restype, argtypes); mirrors include/n2v_hip.h and include/n2v_bine.h one to one
 _i64, _i32, _u64, _f64, _ptr = C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_void_p
+BINE_SEQUENTIAL = 0
+BINE_PARALLEL = 1
 SIGNATURES = {
     "n2v_abi_version": (C.c_int, []),
     "n2v_last_error": (C.c_char_p, []),
@@ -42,6 +44,18 @@ SIGNATURES = {
     "n2v_sgns_train": (C.c_int, [_ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _ptr, _ptr,
                                  _ptr, _i32, C.c_float, C.c_float, _i64, _i64, _i64, _i64, _u64, _u64, _ptr, _i32,
                                  _i32, _ptr]),
+    # include/n2v_bine.h
+    "n2v_bine_spmv": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "n2v_bine_hits_normalise": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "n2v_bine_walk_counts": (C.c_int, [_ptr, _i64, _i64, _i32, _i32, _ptr, _ptr, _ptr]),
+    "n2v_bine_walk_lengths": (C.c_int, [_ptr, _ptr, _ptr, _i64, _i64, _f64, _i32, _u64, _ptr, _ptr]),
+    "n2v_bine_walk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _u64, _ptr, _ptr]),
+    "n2v_bine_neg_pools": (C.c_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _f64, _u64, _ptr, _ptr]),
+    "n2v_bine_init": (C.c_int, [_ptr, _ptr, _i64, _i32, _i32, _u64, _ptr]),
+    "n2v_bine_train_pass": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _ptr,
+                                      _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _f64, _ptr, _i32, _u64, _u64,
+                                      _i32, _i32, _ptr]),
+    "n2v_bine_lambda_step": (C.c_int, [_ptr, _f64, _ptr]),
 }
 
 _lib = None

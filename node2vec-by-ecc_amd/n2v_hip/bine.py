@@ -1,0 +1,309 @@
+"""BiNE path on MI355X: bipartite graph in HBM, every arithmetic step in the HIP kernels behind
+include/n2v_bine.h (BASELINE config 5).
+
+Replaces the pipeline of the reference's src/bine_train.py:433-515 (`train`):
+  GraphUtils.construct_training_graph   (src/bine_graph_utils.py:32-58)   -> BipartiteGraph (host, numpy)
+  calculate_centrality -> nx.hits       (src/bine_graph_utils.py:60-86)   -> BineEngine.calculate_centrality
+  homogeneous_graph_random_walks_for_large_bipartite_graph (:112-131)     -> BineEngine.generate_walks
+  get_negs (LSH pools, src/bine_lsh.py)                                   -> BineEngine.build_negative_pools
+  get_context_and_negatives (:150-191)                                    -> BineEngine.build_occurrences (index only;
+                                                                             windows/negatives are formed in the kernel)
+  init_embedding_vectors, the max_iter loop (src/bine_train.py:183-206,454-504) -> init_embeddings / train
+
+torch is memory, streams and index plumbing (prefix sums, sort of token positions by vertex); there is no
+CPU path: without a GPU every device entry point raises.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_WALK_LEN = 256  # cap of the geometric walk length (P(len > 256) = 0.85^255 ~ 1e-18 at the default 0.15)
+
+
+def derive_seed(seed, k):
+    """Independent 64-bit Philox keys for the pipeline's stages (splitmix64 of seed + k)."""
+    x = (int(seed) + int(k) * 0x9E3779B97F4A7C15 + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+SEED_WALK_U, SEED_WALK_V, SEED_POOL_U, SEED_POOL_V, SEED_INIT, SEED_OCC, SEED_NEG = range(1, 8)
+
+
+class BineConvergenceError(RuntimeError):
+    """networkx 1.11 raises NetworkXError when hits() does not converge in max_iter iterations."""
+
+
+class BipartiteGraph:
+    """Host-side bipartite rating graph (src/bine_graph_utils.py:32-58).
+
+    Vertices: users 0..n_u-1 and items n_u..n_u+n_v-1, each side in ascending label order
+    (`node_u.sort()`, :53-54).  One symmetric CSR (rows ascending) with fp64 ratings; the rating list keeps
+    file order and duplicates (`edge_list`, :45,58) while a repeated (user, item) pair takes its LAST rating
+    everywhere (`edge_dict_u[user][item] = rating`, :46; add_weighted_edges_from, :57)."""
+
+    def __init__(self, users, items, ratings):
+        users = np.asarray(users)
+        items = np.asarray(items)
+        ratings = np.asarray(ratings, dtype=np.float64)
+        if not (len(users) == len(items) == len(ratings)):
+            raise ValueError("users, items and ratings must have the same length")
+        self.user_labels, eu = np.unique(users, return_inverse=True)
+        self.item_labels, ev = np.unique(items, return_inverse=True)
+        self.n_u, self.n_v = len(self.user_labels), len(self.item_labels)
+        self.n = self.n_u + self.n_v
+        E = len(eu)
+        # last rating of every distinct pair
+        key = eu.astype(np.int64) * max(self.n_v, 1) + ev
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        last = np.ones(E, dtype=bool)
+        last[:-1] = ks[1:] != ks[:-1]
+        pair_key = ks[last]
+        pair_w = ratings[order][last]
+        self.edge_u = eu.astype(np.int32)
+        self.edge_v = (ev + self.n_u).astype(np.int32)
+        self.edge_w = pair_w[np.searchsorted(pair_key, key)]
+        # visited_u / visited_v (src/bine_train.py:458-487): a vertex is handled at its first rating
+        first = np.zeros(E, dtype=np.uint8)
+        if E:
+            first[np.unique(eu, return_index=True)[1]] |= 1
+            first[np.unique(ev, return_index=True)[1]] |= 2
+        self.first = first
+        # symmetric CSR over users + items
+        pu = (pair_key // max(self.n_v, 1)).astype(np.int64)
+        pv = (pair_key % max(self.n_v, 1)).astype(np.int64) + self.n_u
+        src = np.concatenate([pu, pv])
+        dst = np.concatenate([pv, pu])
+        ww = np.concatenate([pair_w, pair_w])
+        o = np.lexsort((dst, src))
+        self.col = dst[o].astype(np.int32)
+        self.w = ww[o]
+        self.row_ptr = np.zeros(self.n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(src, minlength=self.n), out=self.row_ptr[1:])
+
+    @property
+    def n_ratings(self):
+        return len(self.edge_u)
+
+    @classmethod
+    def read(cls, filename):
+        """`user<TAB>item<TAB>rating` lines (src/bine_graph_utils.py:37-49)."""
+        users, items, ratings = [], [], []
+        with open(filename, encoding="UTF-8") as fin:
+            for line in fin:
+                if not line.strip():
+                    continue
+                user, item, rating = line.strip().split("\t")
+                users.append(user)
+                items.append(item)
+                ratings.append(float(rating))
+        return cls(users, items, ratings)
+
+    def label_of(self, v):
+        return self.user_labels[v] if v < self.n_u else self.item_labels[v - self.n_u]
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("n2v_hip.bine: no GPU visible (torch.cuda.is_available() is False); "
+                           "this engine has no CPU fallback")
+    return torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+
+
+class BineEngine:
+    """HBM-resident BiNE state for one bipartite graph."""
+
+    def __init__(self, graph: BipartiteGraph, device=None, seed=0):
+        self.lib = _lib.load()
+        self.device = d = _require_gpu(device)
+        self.g = graph
+        self.seed = int(seed)
+        self.row_ptr = torch.from_numpy(graph.row_ptr).to(d)
+        self.col = torch.from_numpy(graph.col).to(d)
+        self.w = torch.from_numpy(graph.w).to(d)
+        self.edge_u = torch.from_numpy(graph.edge_u).to(d)
+        self.edge_v = torch.from_numpy(graph.edge_v).to(d)
+        self.edge_w = torch.from_numpy(graph.edge_w).to(d)
+        self.first = torch.from_numpy(graph.first).to(d)
+        deg = self.row_ptr[1:] - self.row_ptr[:-1]
+        # two-hop path prefix: cum2[e] = number of two-hop paths through CSR entries before e
+        self.cum2 = torch.zeros(graph.col.shape[0] + 1, dtype=torch.int64, device=d)
+        if graph.col.shape[0]:
+            torch.cumsum(deg[self.col.long()], 0, out=self.cum2[1:])
+        self.authority = self.auth_scaled = self.counts = None
+        self.tokens = self.tok_walk = self.walk_off = self.walk_node = None
+        self.n_walks = (0, 0)
+        self.pool = None
+        self.occ_ptr = self.occ_pos = None
+        self.emb = self.ctx = None
+        self.state = torch.zeros(8, dtype=torch.float64, device=d)
+        self.losses = []
+
+    def _stream(self):
+        return _lib.stream_ptr(self.device)
+
+    def _seed(self, k):
+        return derive_seed(self.seed, k)
+
+    # ------------------------------------------------------------------ centrality
+    def calculate_centrality(self, max_iter=100, tol=1.0e-8):
+        """nx.hits(G) of networkx 1.11 (src/bine_graph_utils.py:61): authority scores by power iteration from
+        h = 1/n, max-normalised every iteration, stop at sum|h - h_last| < tol, error after max_iter."""
+        n, d, lib = self.g.n, self.device, self.lib
+        with torch.cuda.device(d):
+            h = torch.full((n,), 1.0 / n, dtype=torch.float64, device=d)
+            hn = torch.empty_like(h)
+            a = torch.empty_like(h)
+            st = torch.zeros(1, dtype=torch.float64, device=d)
+            p = _lib.ptr
+            for it in range(max_iter):
+                _lib.check(lib.n2v_bine_spmv(n, p(self.row_ptr), p(self.col), p(self.w), p(h), p(a), self._stream()))
+                _lib.check(lib.n2v_bine_spmv(n, p(self.row_ptr), p(self.col), p(self.w), p(a), p(hn), self._stream()))
+                _lib.check(lib.n2v_bine_hits_normalise(n, p(hn), p(a), p(h), p(st), self._stream()))
+                h, hn = hn, h
+                if float(st.item()) < tol:
+                    self.authority = a
+                    self.hits_iterations = it + 1
+                    return a
+        raise BineConvergenceError("HITS: power iteration failed to converge in %d iterations" % max_iter)
+
+    # ------------------------------------------------------------------ walks
+    def generate_walks(self, percentage=0.15, maxT=32, minT=1, max_len=MAX_WALK_LEN):
+        """walk_generator (src/bine_train.py:210-222) for --large 1: max(ceil(maxT * authority), minT) restart
+        walks from every vertex of each side, on that side's projection.  Result: one ragged token array
+        (users' walks, then items'), `walk_off`, `walk_node`, `tok_walk`."""
+        if self.authority is None:
+            self.calculate_centrality()
+        g, d, lib, p = self.g, self.device, self.lib, _lib.ptr
+        with torch.cuda.device(d):
+            counts = torch.zeros(g.n, dtype=torch.int32, device=d)
+            auth = torch.zeros(g.n, dtype=torch.float64, device=d)
+            for lo, hi in ((0, g.n_u), (g.n_u, g.n)):
+                _lib.check(lib.n2v_bine_walk_counts(p(self.authority), lo, hi, int(maxT), int(minT), p(counts), p(auth),
+                                                    self._stream()))
+            self.counts, self.auth_scaled = counts, auth
+            ids = torch.arange(g.n, dtype=torch.int32, device=d)
+            walk_node = torch.repeat_interleave(ids, counts.long())
+            nw_u = int(counts[: g.n_u].sum().item())
+            nw = int(walk_node.shape[0])
+            self.n_walks = (nw_u, nw - nw_u)
+            lens = torch.empty(nw, dtype=torch.int32, device=d)
+            sides = ((0, nw_u, self._seed(SEED_WALK_U)), (nw_u, nw - nw_u, self._seed(SEED_WALK_V)))
+            for base, cnt, seed in sides:
+                if cnt:
+                    _lib.check(lib.n2v_bine_walk_lengths(p(self.row_ptr), p(self.cum2), walk_node[base:].data_ptr(), cnt, 0,
+                                                         float(percentage), int(max_len), seed, lens[base:].data_ptr(),
+                                                         self._stream()))
+            walk_off = torch.zeros(nw + 1, dtype=torch.int64, device=d)
+            torch.cumsum(lens.long(), 0, out=walk_off[1:])
+            n_tok = int(walk_off[-1].item())
+            tokens = torch.empty(n_tok, dtype=torch.int32, device=d)
+            for base, cnt, seed in sides:
+                if cnt:
+                    _lib.check(lib.n2v_bine_walk(p(self.row_ptr), p(self.col), p(self.cum2), walk_node[base:].data_ptr(),
+                                                 walk_off[base:].data_ptr(), cnt, 0, seed, p(tokens), self._stream()))
+            self.walk_node, self.walk_off, self.tokens = walk_node, walk_off, tokens
+            self.tok_walk = torch.repeat_interleave(torch.arange(nw, dtype=torch.int32, device=d), lens.long())
+            self.occ_ptr = self.occ_pos = None
+        return self
+
+    def walks_as_lists(self, side):
+        """The walks of one side ('u' or 'v') as lists of labels (gul.walks_u / gul.walks_v)."""
+        nw_u, nw_v = self.n_walks
+        lo, hi = (0, nw_u) if side == "u" else (nw_u, nw_u + nw_v)
+        off = self.walk_off.cpu().numpy()
+        tok = self.tokens.cpu().numpy()
+        return [[self.g.label_of(int(t)) for t in tok[off[i]:off[i + 1]]] for i in range(lo, hi)]
+
+    # ------------------------------------------------------------------ negatives, contexts
+    def build_negative_pools(self, pool_size=200, max_jaccard=1.0 / 128.0):
+        """get_negs (src/bine_graph_utils.py:145-148 -> src/bine_lsh.py:22-51): per vertex `pool_size` vertices of
+        its own side that are not similar to it.  The reference asks a MinHash LSH forest (128 permutations) for
+        the similar ones; here a candidate is refused when its exact Jaccard similarity exceeds `max_jaccard`
+        (default 1/128: less than one expected MinHash collision) — see DESIGN.md 4.7."""
+        g, d, lib, p = self.g, self.device, self.lib, _lib.ptr
+        with torch.cuda.device(d):
+            pool = torch.empty((g.n, int(pool_size)), dtype=torch.int32, device=d)
+            for lo, hi, k in ((0, g.n_u, SEED_POOL_U), (g.n_u, g.n, SEED_POOL_V)):
+                if hi > lo:
+                    _lib.check(lib.n2v_bine_neg_pools(p(self.row_ptr), p(self.col), lo, hi, lo, hi, int(pool_size),
+                                                      float(max_jaccard), self._seed(k), pool[lo:].data_ptr(),
+                                                      self._stream()))
+            self.pool = pool
+        return self
+
+    def build_occurrences(self):
+        """Index of every vertex's occurrences in the walks (the keys and list positions of the reference's
+        context_dict, src/bine_graph_utils.py:161-187): token positions grouped by vertex, ascending."""
+        if self.tokens is None:
+            raise RuntimeError("generate_walks() first")
+        with torch.cuda.device(self.device):
+            tok = self.tokens.long()
+            self.occ_pos = torch.argsort(tok, stable=True)
+            self.occ_ptr = torch.zeros(self.g.n + 1, dtype=torch.int64, device=self.device)
+            torch.cumsum(torch.bincount(tok, minlength=self.g.n), 0, out=self.occ_ptr[1:])
+        return self
+
+    # ------------------------------------------------------------------ embeddings
+    def init_embeddings(self, d=128):
+        """init_embedding_vectors (src/bine_train.py:183-206): U[0,1)^d rows scaled to unit l2 norm for the
+        embedding and the context table of every vertex."""
+        self.dim = int(d)
+        self.stride = next(s for s in (64, 128, 256, 512) if s >= self.dim) if self.dim <= 512 else None
+        if self.stride is None:
+            raise ValueError("d must be <= 512")
+        with torch.cuda.device(self.device):
+            self.emb = torch.empty((self.g.n, self.stride), dtype=torch.float64, device=self.device)
+            self.ctx = torch.empty_like(self.emb)
+            _lib.check(self.lib.n2v_bine_init(_lib.ptr(self.emb), _lib.ptr(self.ctx), self.g.n, self.dim, self.stride,
+                                              self._seed(SEED_INIT), self._stream()))
+        return self
+
+    def train(self, max_iter=50, alpha=0.01, beta=0.01, gamma=0.1, lam=0.01, ws=5, ns=4, epsilon=1e-3,
+              mode="parallel", max_blocks=0, e_range=None, first_iteration=0):
+        """The iteration loop of src/bine_train.py:452-504.  mode='sequential' reproduces the reference's update
+        order with one wavefront (parity tests); 'parallel' is the production mode.  Returns the per-iteration
+        losses; `self.lam` is the final learning rate."""
+        if self.emb is None:
+            self.init_embeddings()
+        if self.pool is None:
+            self.build_negative_pools()
+        if self.occ_ptr is None:
+            self.build_occurrences()
+        md = {"sequential": _lib.BINE_SEQUENTIAL, "parallel": _lib.BINE_PARALLEL}[mode]
+        lib, p = self.lib, _lib.ptr
+        e0, e1 = e_range if e_range is not None else (0, self.g.n_ratings)
+        with torch.cuda.device(self.device):
+            if first_iteration == 0:
+                self.state.copy_(torch.tensor([lam, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float64))
+                self.losses = []
+            for it in range(first_iteration, first_iteration + max_iter):
+                _lib.check(lib.n2v_bine_train_pass(
+                    p(self.edge_u), p(self.edge_v), p(self.edge_w), p(self.first), e0, e1, p(self.emb), p(self.ctx),
+                    self.dim, self.stride, p(self.occ_ptr), p(self.occ_pos), p(self.tokens), p(self.tok_walk),
+                    p(self.walk_off), p(self.pool), int(self.pool.shape[1]), int(ws), int(ns), float(alpha), float(beta),
+                    float(gamma), p(self.state), it, self._seed(SEED_OCC), self._seed(SEED_NEG), md, int(max_blocks),
+                    self._stream()))
+                if self.pre_lambda_hook is not None:
+                    self.pre_lambda_hook(self)
+                loss_now = self.state[1:2].clone()
+                _lib.check(lib.n2v_bine_lambda_step(p(self.state), float(epsilon), self._stream()))
+                st = self.state.tolist()
+                self.losses.append(float(loss_now.item()))
+                if st[3] != 0.0:
+                    break
+            self.lam = float(self.state[0].item())
+        return self.losses
+
+    pre_lambda_hook = None  # multi-GPU: merge replicas and all-reduce the loss before the learning-rate step
+
+    # ------------------------------------------------------------------ results
+    def vectors(self, side, which="embedding"):
+        """float64 [n_side, d] (node_list_u[u]['embedding_vectors'] stacked in label order)."""
+        t = self.emb if which == "embedding" else self.ctx
+        lo, hi = (0, self.g.n_u) if side == "u" else (self.g.n_u, self.g.n)
+        return t[lo:hi, : self.dim].cpu().numpy()

@@ -89,3 +89,19 @@ def make_config_graph(name):
             "sum_deg2": int((deg.astype(np.int64) ** 2).sum()), "max_deg": int(deg.max()),
             "edges_sha256": edges_sha256(u, v)}
     return g, info
+
+
+def bipartite_powerlaw_ratings(n_users, n_items, n_ratings, exponent=0.75, seed=42):
+    """BASELINE config 5's shape: every user rates n_ratings // n_users items drawn from a power-law item
+    popularity p(rank) ~ (rank + 1)^-exponent (duplicate pairs kept: the rating list may repeat a pair, as a
+    ratings file may), ratings uniform in {1..5}.  Returns (users, items, ratings) in user-major order; items
+    that nobody rated do not appear (n_items is the size of the catalogue drawn from)."""
+    rs = np.random.RandomState(seed)
+    per_user = max(1, n_ratings // n_users)
+    cdf = np.cumsum(1.0 / np.power(np.arange(1, n_items + 1, dtype=np.float64), exponent))
+    cdf /= cdf[-1]
+    users = np.repeat(np.arange(n_users, dtype=np.int64), per_user)
+    items = np.searchsorted(cdf, rs.random_sample(users.shape[0])).astype(np.int64)
+    np.minimum(items, n_items - 1, out=items)
+    ratings = rs.randint(1, 6, size=users.shape[0]).astype(np.float64)
+    return users, items, ratings

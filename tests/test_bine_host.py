@@ -1,0 +1,156 @@
+"""CPU tests of the BiNE restatements (oracle/bine_oracle.py) and the host-side graph builder.
+
+The reference's BiNE files cannot run here (see the oracle's header), so the chain is closed statistically:
+the Philox restatement (P) — which the HIP kernels must equal bit for bit (tests/test_gpu_bine.py) — is
+checked against the literal restatement (L) of the reference text: next-vertex distribution uniform over the
+DISTINCT two-hop vertices, geometric walk lengths, HITS direction."""
+import math
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+from scipy import stats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "node2vec-by-ecc_amd"))
+
+from oracle import bine_oracle as bo  # noqa: E402
+
+
+def small_graph(seed=3, n_u=30, n_v=12, per_user=5):
+    from n2v_hip import bine
+    rs = np.random.RandomState(seed)
+    users = np.repeat(np.arange(n_u), per_user)
+    items = rs.randint(0, n_v, size=users.shape[0])       # dense overlaps: multiplicities well above 1
+    ratings = rs.randint(1, 6, size=users.shape[0]).astype(float)
+    return bine.BipartiteGraph(["u%d" % u for u in users], ["i%d" % i for i in items], ratings)
+
+
+def test_bipartite_graph_builder():
+    from n2v_hip import bine
+    g = bine.BipartiteGraph(["u2", "u10", "u2", "u2", "u3"], ["i1", "i1", "i5", "i1", "i5"], [1, 2, 3, 4, 5])
+    assert g.user_labels.tolist() == ["u10", "u2", "u3"]        # string sort, as node_u.sort()
+    assert g.item_labels.tolist() == ["i1", "i5"]
+    assert (g.n_u, g.n_v, g.n_ratings) == (3, 2, 5)
+    assert g.edge_u.tolist() == [1, 0, 1, 1, 2] and g.edge_v.tolist() == [3, 3, 4, 3, 4]
+    assert g.edge_w.tolist() == [4.0, 2.0, 3.0, 4.0, 5.0]       # the repeated (u2, i1) takes its last rating
+    assert g.first.tolist() == [3, 1, 2, 0, 1]
+    # symmetric CSR, rows ascending
+    assert g.row_ptr.tolist() == [0, 1, 3, 4, 6, 8]
+    assert g.col.tolist() == [3, 3, 4, 4, 0, 1, 1, 2]
+    assert g.w.tolist() == [2.0, 4.0, 3.0, 5.0, 2.0, 4.0, 3.0, 5.0]
+
+
+def test_hits_restatement_is_the_top_singular_pair():
+    g = small_graph()
+    a, iters = bo.hits_nx111(g.row_ptr, g.col, g.w)
+    B = np.zeros((g.n_u, g.n_v))
+    for e in range(g.n_ratings):
+        B[g.edge_u[e], g.edge_v[e] - g.n_u] = g.edge_w[e]
+    U, S, Vt = np.linalg.svd(B)
+    for seg, sv in ((a[: g.n_u], np.abs(U[:, 0])), (a[g.n_u:], np.abs(Vt[0]))):
+        assert np.allclose(seg / seg.max(), sv / sv.max(), rtol=0, atol=1e-6)
+    counts, auth = bo.walk_counts(a, 0, g.n_u, 32, 1)
+    assert counts.min() >= 1 and counts.max() == 32 and auth.min() == 0.0 and auth.max() == 1.0
+
+
+def test_first_common_neighbour_thinning_is_uniform_over_distinct_vertices():
+    """(P) vs (L): from a fixed vertex the next vertex must be uniform over the distinct two-hop vertices
+    (the reference's rand.choice over a de-duplicated matrix row), NOT weighted by the number of paths."""
+    g = small_graph()
+    cum2 = bo.two_hop_prefix(g.row_ptr, g.col)
+    for start in (0, 7, g.n_u + 2):
+        distinct = [x for x in bo.projection_rows(g.row_ptr, g.col, start) if x != start]
+        # multiplicities must be non-trivial for this to test anything
+        mult = [len(set(g.col[g.row_ptr[start]:g.row_ptr[start + 1]]) & set(g.col[g.row_ptr[x]:g.row_ptr[x + 1]]))
+                for x in distinct]
+        assert max(mult) > 1
+        n = 6000
+        got = {x: 0 for x in distinct}
+        for gw in range(n):
+            got[bo.device_walk(g.row_ptr, g.col, cum2, start, gw, 2, seed=12345 + start)[1]] += 1
+        chi2, p = stats.chisquare(list(got.values()))
+        assert p > 1e-3, (start, chi2, p)
+        # and the literal restatement agrees with itself on the same test (sanity of the yardstick)
+        rand = random.Random(7)
+        lit = {x: 0 for x in distinct}
+        rows = lambda v: bo.projection_rows(g.row_ptr, g.col, v)  # noqa: E731
+        for _ in range(n):
+            lit[bo.literal_walk(rows, start, -1.0, rand, max_tokens=2)[1]] += 1   # always continue, one step
+        assert stats.chi2_contingency([list(got.values()), list(lit.values())])[1] > 1e-3
+
+
+def test_walk_lengths_are_geometric():
+    g = small_graph()
+    cum2 = bo.two_hop_prefix(g.row_ptr, g.col)
+    p = 0.15
+    lens = np.array([bo.walk_length(g.row_ptr, cum2, 0, gw, p, 256, seed=99) for gw in range(20000)])
+    # P(len = k) = p (1-p)^(k-1)
+    ks = np.arange(1, 25)
+    exp = len(lens) * p * (1 - p) ** (ks - 1)
+    obs = np.array([(lens == k).sum() for k in ks])
+    chi2 = ((obs - exp) ** 2 / exp).sum()
+    assert stats.chi2.sf(chi2, len(ks) - 1) > 1e-3
+    rand = random.Random(1)
+    lit = np.array([len(bo.literal_walk(lambda v: bo.projection_rows(g.row_ptr, g.col, v), 0, p, rand))
+                    for _ in range(4000)])
+    assert abs(lit.mean() - lens.mean()) < 0.35
+
+
+def test_dead_end_start_yields_single_token():
+    from n2v_hip import bine
+    g = bine.BipartiteGraph(["u0", "u1", "u1"], ["i0", "i1", "i2"], [1, 1, 1])   # u0 alone on i0
+    cum2 = bo.two_hop_prefix(g.row_ptr, g.col)
+    assert bo.walk_length(g.row_ptr, cum2, 0, 0, 0.0, 256, 1) == 1
+    assert bo.walk_length(g.row_ptr, cum2, g.n_u + 1, 0, 0.0, 8, 1) == 8       # i1 - u1 - i2: keeps walking
+    assert bo.device_walk(g.row_ptr, g.col, cum2, g.n_u + 1, 0, 4, 5) == [3, 4, 3, 4]
+
+
+def test_negative_pool_excludes_self_and_similar():
+    g = small_graph(n_u=60, n_v=40, per_user=3)
+    for v in (0, 5, g.n_u + 1):
+        lo, hi = (0, g.n_u) if v < g.n_u else (g.n_u, g.n)
+        pool = bo.neg_pool(g.row_ptr, g.col, lo, hi, v, 50, 0.2, seed=4)
+        assert all(lo <= c < hi and c != v for c in pool)
+        nv = set(g.col[g.row_ptr[v]:g.row_ptr[v + 1]])
+        jac = [len(nv & set(g.col[g.row_ptr[c]:g.row_ptr[c + 1]])) / len(nv | set(g.col[g.row_ptr[c]:g.row_ptr[c + 1]]))
+               for c in pool]
+        assert np.mean(np.array(jac) <= 0.2) > 0.95   # the 16-draw thinning may give up, rarely
+
+
+def test_training_restatement_runs_and_steps_lambda():
+    g = small_graph(n_u=20, n_v=10, per_user=4)
+    cum2 = bo.two_hop_prefix(g.row_ptr, g.col)
+    a, _ = bo.hits_nx111(g.row_ptr, g.col, g.w)
+    tokens, tok_walk, walk_off = [], [], [0]
+    for lo, hi, seed in ((0, g.n_u, 1), (g.n_u, g.n, 2)):
+        counts, _ = bo.walk_counts(a, lo, hi, 4, 1)
+        gw = 0
+        for v in range(lo, hi):
+            for _ in range(int(counts[v - lo])):
+                L = bo.walk_length(g.row_ptr, cum2, v, gw, 0.15, 256, seed)
+                wk = bo.device_walk(g.row_ptr, g.col, cum2, v, gw, L, seed)
+                tok_walk.extend([len(walk_off) - 1] * len(wk))
+                tokens.extend(wk)
+                walk_off.append(len(tokens))
+                gw += 1
+    tokens = np.array(tokens)
+    order = np.argsort(tokens, kind="stable")
+    occ_ptr = np.concatenate([[0], np.cumsum(np.bincount(tokens, minlength=g.n))])
+    pool = [bo.neg_pool(g.row_ptr, g.col, *((0, g.n_u) if v < g.n_u else (g.n_u, g.n)), v, 8, 0.5, 3) for v in range(g.n)]
+    emb, ctx = bo.init_rows(g.n, 8, 5)
+    assert np.allclose((emb ** 2).sum(1), 1.0) and emb.min() >= 0
+    lam, losses = bo.train(g.edge_u, g.edge_v, g.edge_w, emb, ctx, occ_ptr, order, tokens, np.array(tok_walk),
+                           np.array(walk_off), pool, 5, 4, 0.01, 0.01, 0.1, 0.01, 6, 11, 12)
+    assert len(losses) == 6 and all(math.isfinite(x) for x in losses)
+    # the learning rate follows the loss-driven rule of src/bine_train.py:495-500
+    want, last = 0.01, 0.0
+    for x in losses:
+        want = want * 1.05 if last > x else want * 0.95
+        last = x
+    assert lam == want
+    e0, _ = bo.init_rows(g.n, 8, 5)
+    assert np.abs(emb - e0).max() > 1e-4

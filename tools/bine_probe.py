@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Timing of the BiNE path at BASELINE config 5's shape (or a scaled-down one) on one MI355X.
+
+    python tools/bine_probe.py [--users 500000 --items 500000 --ratings 20000000 --dim 256 --iters 5]
+Prints one JSON object: per-stage seconds and the training pass's achieved algorithmic bandwidth
+(rows read + written, counted by the kernel, x dim x 8 B / pass time; peak 8 TB/s)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "node2vec-by-ecc_amd"))
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=500_000)
+    ap.add_argument("--items", type=int, default=500_000)
+    ap.add_argument("--ratings", type=int, default=20_000_000)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--maxT", type=int, default=32)
+    ap.add_argument("--pool", type=int, default=200)
+    ap.add_argument("--max-blocks", type=int, default=0)
+    args = ap.parse_args()
+    from n2v_hip import bine, synth
+
+    out = {"config": vars(args)}
+    sync = torch.cuda.synchronize
+
+    def timed(name, fn):
+        sync()
+        t0 = time.perf_counter()
+        r = fn()
+        sync()
+        out[name + "_s"] = time.perf_counter() - t0
+        print("[bine] %-22s %.3f s" % (name, out[name + "_s"]), file=sys.stderr, flush=True)
+        return r
+
+    t0 = time.perf_counter()
+    u, i, r = synth.bipartite_powerlaw_ratings(args.users, args.items, args.ratings)
+    g = bine.BipartiteGraph(u, i, r)
+    out["host_graph_s"] = time.perf_counter() - t0
+    deg = np.diff(g.row_ptr)
+    out["graph"] = {"n_u": g.n_u, "n_v": g.n_v, "ratings": g.n_ratings, "nnz": int(g.col.shape[0]),
+                    "max_deg_u": int(deg[: g.n_u].max()), "max_deg_v": int(deg[g.n_u:].max())}
+    print("[bine] graph", out["graph"], "%.1f s" % out["host_graph_s"], file=sys.stderr, flush=True)
+    e = timed("upload", lambda: bine.BineEngine(g, device="cuda:0", seed=42))
+    timed("hits", e.calculate_centrality)
+    out["hits_iterations"] = e.hits_iterations
+    timed("walks", lambda: e.generate_walks(0.15, args.maxT, 1))
+    out["walks"] = {"n_walks_u": e.n_walks[0], "n_walks_v": e.n_walks[1], "tokens": int(e.tokens.shape[0])}
+    timed("neg_pools", lambda: e.build_negative_pools(args.pool))
+    timed("occurrences", e.build_occurrences)
+    timed("init", lambda: e.init_embeddings(args.dim))
+    timed("train_warmup_1iter", lambda: e.train(max_iter=1, max_blocks=args.max_blocks))
+    rows0 = float(e.state[4].item())
+    losses = timed("train", lambda: e.train(max_iter=args.iters, max_blocks=args.max_blocks))
+    rows = float(e.state[4].item())
+    per = out["train_s"] / len(losses)
+    out["train"] = {"iterations": len(losses), "seconds_per_iteration": per, "losses": losses, "lam": e.lam,
+                    "rows_per_iteration": rows / len(losses),
+                    "algorithmic_GBps": rows / len(losses) * e.dim * 8 / per / 1e9,
+                    "frac_of_8TBps": rows / len(losses) * e.dim * 8 / per / 8e12,
+                    "ratings_per_s": g.n_ratings / per}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
