@@ -99,15 +99,21 @@ int n2v_bine_init(double* emb, double* ctx, int64_t n, int32_t dim, int32_t row_
  * Occurrence index: occ_ptr int64[n+1], occ_pos int64[n_tokens] (token positions of each vertex,
  * ascending), tokens int32[n_tokens], tok_walk int32[n_tokens] (walk of each token), walk_off
  * int64[n_walks+1]; both sides in one token array (walks of users, then walks of items).
- * state: double[8] = {lam, loss, last_loss, stop, rows, -, -, -}; the pass adds its loss to state[1] and the
- * number of embedding rows it read + wrote (algorithmic traffic = rows * dim * 8 B) to state[4].
+ * state: double[8] = {lam, loss, last_loss, stop, rows, -, work counter (uint64 bits), -}; the pass adds its loss
+ * to state[1] and the number of embedding rows it read + wrote (algorithmic traffic = rows * dim * 8 B) to
+ * state[4]; state[6] hands out chunks of ratings to the wavefronts and must be 0 on entry
+ * (n2v_bine_lambda_step resets it).
  * mode N2V_BINE_SEQUENTIAL: one wavefront walks the list in order with plain loads/stores — the
  * reference's exact update order (used for parity tests, small inputs).  N2V_BINE_PARALLEL:
  * wavefronts take ratings e, e+W, ...; rows are read at agent scope and updated with fp64 atomic
- * adds (no update lost; Hogwild ordering).  Ratings [e_begin, e_end) are processed (a rank's
- * shard); `first` is indexed by the global e.                                               */
+ * adds (no update lost; Hogwild ordering).  N2V_BINE_PARALLEL_STORE: the same, except that the context rows
+ * of an occurrence (its centre and negatives) are written back whole with agent-scope stores — the fp64
+ * atomic rate is what bounds the pass, and these rows are shared only when a vertex happens to be another
+ * wavefront's negative at that moment (that racing update is then lost).  Ratings [e_begin, e_end) are
+ * processed (a rank's shard); `first` is indexed by the global e.                                               */
 #define N2V_BINE_SEQUENTIAL 0
 #define N2V_BINE_PARALLEL 1
+#define N2V_BINE_PARALLEL_STORE 2
 int n2v_bine_train_pass(const int32_t* edge_u, const int32_t* edge_v, const double* edge_w,
                         const uint8_t* first, int64_t e_begin, int64_t e_end, double* emb, double* ctx,
                         int32_t dim, int32_t row_stride, const int64_t* occ_ptr, const int64_t* occ_pos,
@@ -117,7 +123,7 @@ int n2v_bine_train_pass(const int32_t* edge_u, const int32_t* edge_v, const doub
                         uint64_t seed_neg, int32_t mode, int32_t max_blocks, void* stream);
 
 /* End of an iteration (src/bine_train.py:495-502): lam *= 1.05 if last_loss > loss else 0.95;
- * stop = |loss - last_loss| < epsilon; last_loss = loss; loss = 0.                           */
+ * stop = |loss - last_loss| < epsilon; last_loss = loss; loss = 0; work counter = 0.         */
 int n2v_bine_lambda_step(double* state, double epsilon, void* stream);
 
 #ifdef __cplusplus

@@ -45,10 +45,58 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
-__device__ __forceinline__ double wave_sum_d(double x) {  // identical in every lane (a+b == b+a)
+// xor-butterfly exchange of a double with lane ^ M: DPP quad permutes for M = 1, 2, ds_swizzle for 4, 8, 16
+// (no address register, unlike ds_bpermute), a full shuffle for 32.
+template <int M>
+__device__ __forceinline__ double xchg(double x) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, x);
+    int lo = (int)(uint32_t)b, hi = (int)(uint32_t)(b >> 32);
+    if constexpr (M == 1) {
+        lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true);
+    } else if constexpr (M == 2) {
+        lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, true);
+    } else if constexpr (M == 32) {
+        lo = __shfl_xor(lo, 32);
+        hi = __shfl_xor(hi, 32);
+    } else {
+        lo = __builtin_amdgcn_ds_swizzle(lo, (M << 10) | 0x1f);
+        hi = __builtin_amdgcn_ds_swizzle(hi, (M << 10) | 0x1f);
+    }
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+// Wave-wide sums of N values at once (the N butterflies are independent, so their latencies overlap);
+// every lane ends with the same totals (a+b == b+a at every stage).
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double (&x)[N]) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    for (int j = 0; j < N; ++j) x[j] += xchg<32>(x[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] += xchg<16>(x[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] += xchg<8>(x[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] += xchg<4>(x[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] += xchg<2>(x[j]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] += xchg<1>(x[j]);
+}
+__device__ __forceinline__ double wave_sum_d(double x) {
+    double v[1] = {x};
+    wave_sum_n<1>(v);
+    return v[0];
+}
+
+// Values that are equal in all 64 lanes but reach us through vector registers (shuffles, vector loads):
+// v_readfirstlane makes them scalar, so addresses derived from them live in SGPRs and loads from them
+// become scalar loads — the training kernel's row data then has the VGPRs to itself.
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // ------------------------------------------------------------------------------------ HITS
@@ -380,41 +428,49 @@ __device__ __forceinline__ uint32_t floyd_sample(uint32_t n, uint32_t m, int lan
 // skip_gram(c, z, negs) for every context z.  Returns nothing; adds to `loss` in the reference's order.
 template <int VPL, int NT, int MODE>
 __device__ __forceinline__ void node_block(const TrainArgs& a, int32_t c, double pa, double lam, int lane, double& loss,
-                                           uint32_t& rows) {
+                                           uint32_t& rows, double* th0) {
     const double pl = pa * lam;
-    const int64_t ob = a.occ_ptr[c];
-    const uint32_t n_occ = (uint32_t)(a.occ_ptr[c + 1] - ob);
+    const int64_t ob = uni64(a.occ_ptr[c]);
+    const uint32_t n_occ = (uint32_t)uni((int32_t)(a.occ_ptr[c + 1] - ob));
     const uint32_t m = n_occ < 10u ? n_occ : 10u;
-    uint32_t rocc[12];
-    philox4(a.seed_occ, (uint32_t)c, (uint32_t)a.iteration, 0u, 0u, *reinterpret_cast<uint32_t(*)[4]>(&rocc[0]));
-    philox4(a.seed_occ, (uint32_t)c, (uint32_t)a.iteration, 1u, 0u, *reinterpret_cast<uint32_t(*)[4]>(&rocc[4]));
-    philox4(a.seed_occ, (uint32_t)c, (uint32_t)a.iteration, 2u, 0u, *reinterpret_cast<uint32_t(*)[4]>(&rocc[8]));
+    uint32_t ra[4], rb4[4], rc[4];
+    philox4(a.seed_occ, (uint32_t)c, (uint32_t)a.iteration, 0u, 0u, ra);
+    philox4(a.seed_occ, (uint32_t)c, (uint32_t)a.iteration, 1u, 0u, rb4);
+    philox4(a.seed_occ, (uint32_t)c, (uint32_t)a.iteration, 2u, 0u, rc);
     const uint32_t my_occ = floyd_sample(n_occ, m, lane, [&](uint32_t k) {
-        uint32_t w = rocc[0];
+        uint32_t w0 = ra[0], w1 = rb4[0], w2 = rc[0];
 #pragma unroll
-        for (int q = 1; q < 10; ++q) w = (k == (uint32_t)q) ? rocc[q] : w;
-        return w;
+        for (int q = 1; q < 4; ++q) {
+            const bool hit = (k & 3u) == (uint32_t)q;
+            w0 = hit ? ra[q] : w0;
+            w1 = hit ? rb4[q] : w1;
+            w2 = hit ? rc[q] : w2;
+        }
+        return k < 4u ? w0 : (k < 8u ? w1 : w2);
     });
     const int stride = a.row_stride;
     for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t idx = (uint32_t)__shfl((int)my_occ, (int)k);
-        const int64_t o = a.occ_pos[ob + idx];
-        const int32_t wk = a.tok_walk[o];
-        const int64_t w0 = a.walk_off[wk], w1 = a.walk_off[wk + 1];
+        const uint32_t idx = (uint32_t)uni(__shfl((int)my_occ, (int)k));
+        const int64_t o = uni64(a.occ_pos[ob + idx]);
+        const int32_t wk = uni(a.tok_walk[o]);
+        const int64_t w0 = uni64(a.walk_off[wk]), w1 = uni64(a.walk_off[wk + 1]);
         const int64_t s = o - a.ws > w0 ? o - a.ws : w0;            // max(0, iter - win_size) within the walk
         const int64_t e = o + a.ws + 1 < w1 ? o + a.ws + 1 : w1;    // min(len, iter + win_size + 1)
         const int nwin = (int)(e - s);
         const int32_t mytok = lane < nwin ? a.tokens[s + lane] : -1;
         // negatives: distinct pool slots; dropped when in the window or already taken
-        uint32_t rn[8];
-        philox4(a.seed_neg, (uint32_t)o, (uint32_t)((uint64_t)o >> 32), 0u, 0u, *reinterpret_cast<uint32_t(*)[4]>(&rn[0]));
-        philox4(a.seed_neg, (uint32_t)o, (uint32_t)((uint64_t)o >> 32), 1u, 0u, *reinterpret_cast<uint32_t(*)[4]>(&rn[4]));
+        uint32_t rn0[4], rn1[4];
+        philox4(a.seed_neg, (uint32_t)o, (uint32_t)((uint64_t)o >> 32), 0u, 0u, rn0);
+        philox4(a.seed_neg, (uint32_t)o, (uint32_t)((uint64_t)o >> 32), 1u, 0u, rn1);
         const uint32_t m2 = (uint32_t)a.ns < (uint32_t)a.pool_size ? (uint32_t)a.ns : (uint32_t)a.pool_size;
         const uint32_t my_slot = floyd_sample((uint32_t)a.pool_size, m2, lane, [&](uint32_t q) {
-            uint32_t w = rn[0];
+            uint32_t w0 = rn0[0], w1 = rn1[0];
 #pragma unroll
-            for (int z = 1; z < 8; ++z) w = (q == (uint32_t)z) ? rn[z] : w;
-            return w;
+            for (int z = 1; z < 4; ++z) {
+                w0 = ((q & 3u) == (uint32_t)z) ? rn0[z] : w0;
+                w1 = ((q & 3u) == (uint32_t)z) ? rn1[z] : w1;
+            }
+            return q < 4u ? w0 : w1;
         });
         int32_t my_neg = -1;
         if (lane < (int)m2) my_neg = a.pool[(int64_t)c * a.pool_size + my_slot];
@@ -426,7 +482,7 @@ __device__ __forceinline__ void node_block(const TrainArgs& a, int32_t c, double
 #pragma unroll
         for (int q = 0; q < NT - 1; ++q) {
             if (q < (int)m2) {
-                const int32_t cand = __shfl(my_neg, q);
+                const int32_t cand = uni(__shfl(my_neg, q));
                 bool drop = __ballot(mytok == cand) != 0ull;  // in the window (src/bine_graph_utils.py:179-180)
 #pragma unroll
                 for (int z = 0; z < NT; ++z) drop = drop || (z < nt && tgt[z] == cand);  // I_z is a dict: one entry per vertex
@@ -437,38 +493,77 @@ __device__ __forceinline__ void node_block(const TrainArgs& a, int32_t c, double
                 }
             }
         }
-        DRow<VPL> th[NT], dl[NT];
+        // target rows live in registers across the window; in PARALLEL mode the values as loaded are parked in
+        // this lane's own LDS slots so that the commit can add exactly (final - loaded) atomically
+        DRow<VPL> th[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            if (j < nt) th[j] = load_row<VPL, MODE>(a.ctx, tgt[j], stride, lane);
+            if (j < nt) {
+                th[j] = load_row<VPL, MODE>(a.ctx, tgt[j], stride, lane);
+                if constexpr (MODE == N2V_BINE_PARALLEL) {
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) dl[j].v[i] = 0.0;
+                    for (int i = 0; i < VPL; ++i) th0[(j * VPL + i) * 64 + lane] = th[j].v[i];
+                }
+            }
         }
         rows += 2u * (uint32_t)nt;
-        for (int p = 0; p < nwin; ++p) {
-            const int32_t z = __shfl(mytok, p);
-            if (z == c) continue;  // `if walk[index] == walk[iter]: continue`
-            const DRow<VPL> V = load_row<VPL, MODE>(a.emb, z, stride, lane);
+        // contexts: window positions whose token differs from the centre (`if walk[index] == walk[iter]: continue`)
+        uint64_t todo = __ballot(lane < nwin && mytok != c);
+        DRow<VPL> Vn;
+        int32_t zn = -1;
+        if (todo) {
+            zn = uni(__shfl(mytok, (int)__builtin_ctzll(todo)));
+            Vn = load_row<VPL, MODE>(a.emb, zn, stride, lane);
+        }
+        while (todo) {
+            todo &= todo - 1;
+            const int32_t z = zn;
+            const DRow<VPL> V = Vn;
+            bool fetched = false;
+            if (todo) {
+                zn = uni(__shfl(mytok, (int)__builtin_ctzll(todo)));
+                // PARALLEL: fetch the next context row now, so its latency hides behind this context's arithmetic
+                // and atomics (not when it is the same vertex: that row is about to change)
+                if (MODE != N2V_BINE_SEQUENTIAL && zn != z) {
+                    Vn = load_row<VPL, MODE>(a.emb, zn, stride, lane);
+                    fetched = true;
+                }
+            }
             DRow<VPL> upd;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) upd.v[i] = 0.0;
             double l = 0.0;
+            double dots[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) sacc += V.v[i] * th[j].v[i];
+                dots[j] = j < nt ? sacc : 0.0;
+            }
+            wave_sum_n<NT>(dots);  // the targets' rows are distinct, so the dots do not depend on each other's updates
+            // the sigmoid / log chain of target j is evaluated by lane j alone (one pass of exp and log for all
+            // targets instead of one per target), then the coefficients and loss terms return by readlane
+            double mydot = dots[0];
+#pragma unroll
+            for (int j = 1; j < NT; ++j) mydot = lane == j ? dots[j] : mydot;
+            const double ind = lane == 0 ? 1.0 : 0.0;  // I_z: 1 for the centre, 0 for a negative
+            const double X = fmax(mydot, 0.0);
+            const double sig = 1.0 / (1.0 + exp(-X * 1.0));
+            const double mycoef = pl * (ind - sig);
+            const double one_m = 1.0 - sig;
+            // math.log(0) raises -> the term is skipped (src/bine_train.py:268-271)
+            const double myterm = one_m > 0.0 ? pa * (ind * log(sig) + (1.0 - ind) * log(one_m)) : 0.0;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (j < nt) {
-                    const double ind = j == 0 ? 1.0 : 0.0;  // I_z
-                    const double X = fmax(dot_row<VPL>(V, th[j]), 0.0);
-                    const double sig = 1.0 / (1.0 + exp(-X * 1.0));
-                    const double coef = pl * (ind - sig);
+                    const double coef = __builtin_bit_cast(double, uni64(__builtin_bit_cast(int64_t, __shfl(mycoef, j))));
 #pragma unroll
                     for (int i = 0; i < VPL; ++i) {
                         upd.v[i] = upd.v[i] + coef * th[j].v[i];
-                        const double dv = coef * V.v[i];
-                        th[j].v[i] = th[j].v[i] + dv;
-                        dl[j].v[i] = dl[j].v[i] + dv;
+                        th[j].v[i] = th[j].v[i] + coef * V.v[i];
                     }
-                    const double one_m = 1.0 - sig;
-                    if (one_m > 0.0) l += pa * (ind * log(sig) + (1.0 - ind) * log(one_m));  // math.log(0) raises -> skipped
+                    l += __shfl(myterm, j);
                 }
             }
             DRow<VPL> nowV;
@@ -477,48 +572,96 @@ __device__ __forceinline__ void node_block(const TrainArgs& a, int32_t c, double
             commit_row<VPL, MODE>(a.emb, z, stride, lane, nowV, upd);
             loss += l;
             rows += 2u;
+            if (todo && !fetched) Vn = load_row<VPL, MODE>(a.emb, zn, stride, lane);
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-            if (j < nt) commit_row<VPL, MODE>(a.ctx, tgt[j], stride, lane, th[j], dl[j]);
+            if (j < nt) {
+                if constexpr (MODE == N2V_BINE_PARALLEL_STORE) {
+                    // context rows are written back whole at agent scope: a row is shared only when a vertex is,
+                    // at that moment, also somebody's negative — the racing update is then lost, Hogwild-style
+                    double* q = a.ctx + (int64_t)tgt[j] * stride + lane;
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i)
+                        __hip_atomic_store(reinterpret_cast<uint64_t*>(q + i * 64), __builtin_bit_cast(uint64_t, th[j].v[i]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    DRow<VPL> dl;
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i)
+                        dl.v[i] = MODE == N2V_BINE_PARALLEL ? th[j].v[i] - th0[(j * VPL + i) * 64 + lane] : 0.0;
+                    commit_row<VPL, MODE>(a.ctx, tgt[j], stride, lane, th[j], dl);
+                }
+            }
     }
 }
 
 template <int VPL, int NT, int MODE>
-__global__ void __launch_bounds__(256) bine_train_kernel(TrainArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT > 5 || VPL > 4 ? 2 : (VPL == 4 ? 3 : 4))))
+bine_train_kernel(TrainArgs a) {
+    extern __shared__ double th0_all[];  // PARALLEL: [waves per block][NT][VPL][64]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wpb = blockDim.x >> 6;
-    const int64_t nw = (int64_t)gridDim.x * wpb;
+    double* th0 = th0_all + wv * (NT * VPL * 64);
     const double lam = a.state[0];
     const double gl = a.gamma * lam;
     const int stride = a.row_stride;
     double loss = 0.0;
     uint32_t rows = 0;  // embedding rows read + written by this wave (algorithmic traffic, state[4])
-    for (int64_t e = a.e_begin + (int64_t)blockIdx.x * wpb + wv; e < a.e_end; e += nw) {
-        const int32_t u = a.edge_u[e], v = a.edge_v[e];
-        const double w = a.edge_w[e];
-        const uint8_t f = a.first[e];
-        if (f & 1) node_block<VPL, NT, MODE>(a, u, a.alpha, lam, lane, loss, rows);
-        if (f & 2) node_block<VPL, NT, MODE>(a, v, a.beta, lam, lane, loss, rows);
-        // KL_divergence (src/bine_train.py:277-309)
-        const DRow<VPL> U = load_row<VPL, MODE>(a.emb, u, stride, lane);
-        const DRow<VPL> V = load_row<VPL, MODE>(a.emb, v, stride, lane);
-        const double X = fmax(dot_row<VPL>(U, V), 0.0);
-        const double sig = 1.0 / (1.0 + exp(-X * 1.0));
-        const double g = gl * ((w * (1.0 - sig)) * 1.0 / kLn10);
-        DRow<VPL> du, dv, nu, nv;
+    // Work is handed out in chunks of kChunk consecutive ratings through a counter in state[6]: the cost of a
+    // rating varies by orders of magnitude (first-seen vertices carry their skip-gram block, and those cluster
+    // at the head of the list and at regular strides), so any static assignment leaves most waves idle.
+    // One wave (SEQUENTIAL) simply takes the chunks in order.
+    constexpr int64_t kChunk = 16;
+    unsigned long long* next_chunk = reinterpret_cast<unsigned long long*>(a.state + 6);
+    for (;;) {
+        unsigned long long got = 0;
+        if (lane == 0) got = __hip_atomic_fetch_add(next_chunk, (unsigned long long)kChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t c0 = a.e_begin + uni64((int64_t)got);
+        if (c0 >= a.e_end) break;
+        const int64_t c1 = c0 + kChunk < a.e_end ? c0 + kChunk : a.e_end;
+        // Consecutive ratings usually share their user (rating files are grouped by user): its embedding row is
+        // carried in registers across them — the reference's own sequence U += g*V, U += g'*V', ... — and
+        // committed once when the user changes or the chunk ends.
+        int32_t held_u = -1;
+        DRow<VPL> U, dU;
+        for (int64_t e = c0; e < c1; ++e) {
+            const int32_t u = uni(a.edge_u[e]), v = uni(a.edge_v[e]);
+            const double w = __builtin_bit_cast(double, uni64(__builtin_bit_cast(int64_t, a.edge_w[e])));
+            const int32_t f = uni((int32_t)a.first[e]);
+            if (f != 0 && held_u >= 0) {  // a skip-gram block may touch any embedding row: hand ours back first
+                commit_row<VPL, MODE>(a.emb, held_u, stride, lane, U, dU);
+                held_u = -1;
+            }
+            for (int side = 0; side < 2; ++side)  // the user's block, then the item's (src/bine_train.py:462,475)
+                if (f & (1 << side)) node_block<VPL, NT, MODE>(a, side ? v : u, side ? a.beta : a.alpha, lam, lane, loss, rows, th0);
+            // KL_divergence (src/bine_train.py:277-309)
+            if (u != held_u) {
+                if (held_u >= 0) commit_row<VPL, MODE>(a.emb, held_u, stride, lane, U, dU);
+                U = load_row<VPL, MODE>(a.emb, u, stride, lane);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            du.v[i] = g * V.v[i];
-            dv.v[i] = g * U.v[i];
-            nu.v[i] = U.v[i] + du.v[i];
-            nv.v[i] = V.v[i] + dv.v[i];
+                for (int i = 0; i < VPL; ++i) dU.v[i] = 0.0;
+                held_u = u;
+                rows += 2u;
+            }
+            const DRow<VPL> V = load_row<VPL, MODE>(a.emb, v, stride, lane);
+            const double X = fmax(dot_row<VPL>(U, V), 0.0);
+            const double sig = 1.0 / (1.0 + exp(-X * 1.0));
+            const double g = gl * ((w * (1.0 - sig)) * 1.0 / kLn10);
+            DRow<VPL> dv, nv;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const double du = g * V.v[i];
+                dv.v[i] = g * U.v[i];
+                nv.v[i] = V.v[i] + dv.v[i];
+                U.v[i] = U.v[i] + du;
+                dU.v[i] = dU.v[i] + du;
+            }
+            commit_row<VPL, MODE>(a.emb, v, stride, lane, nv, dv);
+            loss += a.gamma * w * log(sig);
+            rows += 2u;
         }
-        commit_row<VPL, MODE>(a.emb, u, stride, lane, nu, du);
-        commit_row<VPL, MODE>(a.emb, v, stride, lane, nv, dv);
-        loss += a.gamma * w * log(sig);
-        rows += 4u;
+        if (held_u >= 0) commit_row<VPL, MODE>(a.emb, held_u, stride, lane, U, dU);
     }
     if (lane == 0) {
         __hip_atomic_fetch_add(&a.state[1], loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -532,6 +675,7 @@ __global__ void lambda_step_kernel(double* state, double epsilon) {
     state[3] = fabs(loss - last) < epsilon ? 1.0 : 0.0;
     state[2] = loss;
     state[1] = 0.0;
+    *reinterpret_cast<unsigned long long*>(state + 6) = 0ull;  // work counter of the next pass
 }
 
 template <int VPL, int NT>
@@ -543,7 +687,12 @@ int launch_train(const TrainArgs& a, int mode, int max_blocks, hipStream_t st) {
         int64_t blocks = (n + 3) / 4;
         const int64_t cap = max_blocks > 0 ? max_blocks : 2048;
         if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL((bine_train_kernel<VPL, NT, N2V_BINE_PARALLEL>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        if (mode == N2V_BINE_PARALLEL)
+            hipLaunchKernelGGL((bine_train_kernel<VPL, NT, N2V_BINE_PARALLEL>), dim3((unsigned)blocks), dim3(256),
+                               4 * NT * VPL * 64 * sizeof(double), st, a);
+        else
+            hipLaunchKernelGGL((bine_train_kernel<VPL, NT, N2V_BINE_PARALLEL_STORE>), dim3((unsigned)blocks), dim3(256), 0,
+                               st, a);
     }
     return n2v::check_launch("n2v_bine_train_pass");
 }
@@ -640,7 +789,7 @@ extern "C" int n2v_bine_train_pass(const int32_t* edge_u, const int32_t* edge_v,
                          (int)row_stride, (int)ws, (int)ns, (int)pool_size);
     if (row_stride != 64 && row_stride != 128 && row_stride != 256 && row_stride != 512)
         return n2v::fail(N2V_ERR_INVALID, "n2v_bine_train_pass: row_stride must be 64, 128, 256 or 512 (got %d)", (int)row_stride);
-    if (mode != N2V_BINE_SEQUENTIAL && mode != N2V_BINE_PARALLEL)
+    if (mode != N2V_BINE_SEQUENTIAL && mode != N2V_BINE_PARALLEL && mode != N2V_BINE_PARALLEL_STORE)
         return n2v::fail(N2V_ERR_INVALID, "n2v_bine_train_pass: unknown mode %d", (int)mode);
     if (e_end == e_begin) return N2V_OK;
     if (!edge_u || !edge_v || !edge_w || !first || !emb || !ctx || !occ_ptr || !occ_pos || !tokens || !tok_walk ||

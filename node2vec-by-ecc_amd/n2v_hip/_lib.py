@@ -22,6 +22,7 @@ RNG_PHILOX = 1
 _i64, _i32, _u64, _f64, _ptr = C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_void_p
 BINE_SEQUENTIAL = 0
 BINE_PARALLEL = 1
+BINE_PARALLEL_STORE = 2
 SIGNATURES = {
     "n2v_abi_version": (C.c_int, []),
     "n2v_last_error": (C.c_char_p, []),

@@ -18,6 +18,7 @@ import torch
 
 from . import _lib
 
+AUTO_STORE_MIN_VERTICES = 131072  # mode='parallel': context rows by atomics below, by whole-row stores above
 MAX_WALK_LEN = 256  # cap of the geometric walk length (P(len > 256) = 0.85^255 ~ 1e-18 at the default 0.15)
 
 
@@ -266,7 +267,8 @@ class BineEngine:
     def train(self, max_iter=50, alpha=0.01, beta=0.01, gamma=0.1, lam=0.01, ws=5, ns=4, epsilon=1e-3,
               mode="parallel", max_blocks=0, e_range=None, first_iteration=0):
         """The iteration loop of src/bine_train.py:452-504.  mode='sequential' reproduces the reference's update
-        order with one wavefront (parity tests); 'parallel' is the production mode.  Returns the per-iteration
+        order with one wavefront (parity tests); 'atomic' / 'store' are the two parallel variants of
+        include/n2v_bine.h, 'parallel' picks between them by graph size.  Returns the per-iteration
         losses; `self.lam` is the final learning rate."""
         if self.emb is None:
             self.init_embeddings()
@@ -274,7 +276,10 @@ class BineEngine:
             self.build_negative_pools()
         if self.occ_ptr is None:
             self.build_occurrences()
-        md = {"sequential": _lib.BINE_SEQUENTIAL, "parallel": _lib.BINE_PARALLEL}[mode]
+        if mode == "parallel":   # like the SGNS row-sharing policy: lossless atomics while every row is hot
+            mode = "atomic" if self.g.n < AUTO_STORE_MIN_VERTICES else "store"
+        md = {"sequential": _lib.BINE_SEQUENTIAL, "atomic": _lib.BINE_PARALLEL, "store": _lib.BINE_PARALLEL_STORE}[mode]
+        self.mode_used = mode
         lib, p = self.lib, _lib.ptr
         e0, e1 = e_range if e_range is not None else (0, self.g.n_ratings)
         with torch.cuda.device(self.device):

@@ -139,7 +139,8 @@ def test_sequential_training_matches_numpy_restatement(d, ns):
     assert (e.emb[:, d:] == 0).all() and (e.ctx[:, d:] == 0).all()
 
 
-def test_parallel_mode_tracks_sequential_mode(eng):
+@pytest.mark.parametrize("pmode", ["atomic", "store"])
+def test_parallel_mode_tracks_sequential_mode(eng, pmode):
     """Hogwild ordering changes which update sees which, not what is computed: after the same number of
     iterations the losses of the two modes agree closely and the embeddings stay close."""
     eng.init_embeddings(d=32)
@@ -148,17 +149,17 @@ def test_parallel_mode_tracks_sequential_mode(eng):
     es = eng.emb.clone()
     eng.emb.copy_(e0)
     eng.ctx.copy_(c0)
-    par = eng.train(max_iter=4, mode="parallel")
-    assert np.allclose(seq, par, rtol=2e-3)
+    par = eng.train(max_iter=4, mode=pmode)
+    assert np.allclose(seq, par, rtol=2e-3 if pmode == "atomic" else 1e-2)
     assert eng.lam > 0
     rel = ((eng.emb - es).norm() / (es - e0).norm()).item()
-    assert rel < 0.2, rel
+    assert rel < (0.2 if pmode == "atomic" else 0.35), rel
     # deterministic sampling: a second parallel run processes the same occurrences (loss differs only by
     # update order)
     eng.emb.copy_(e0)
     eng.ctx.copy_(c0)
-    par2 = eng.train(max_iter=4, mode="parallel")
-    assert np.allclose(par, par2, rtol=1e-4)
+    par2 = eng.train(max_iter=4, mode=pmode)
+    assert np.allclose(par, par2, rtol=2e-3 if pmode == "atomic" else 1e-2)
 
 
 def test_vectors_accessor_and_walk_lists(eng):

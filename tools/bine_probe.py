@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--maxT", type=int, default=32)
     ap.add_argument("--pool", type=int, default=200)
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--mode", default="parallel", choices=["parallel", "atomic", "store"])
+    ap.add_argument("--split", action="store_true", help="also time a pass with the skip-gram blocks disabled (KL only)")
     args = ap.parse_args()
     from n2v_hip import bine, synth
 
@@ -58,16 +60,27 @@ def main():
     timed("neg_pools", lambda: e.build_negative_pools(args.pool))
     timed("occurrences", e.build_occurrences)
     timed("init", lambda: e.init_embeddings(args.dim))
-    timed("train_warmup_1iter", lambda: e.train(max_iter=1, max_blocks=args.max_blocks))
+    timed("train_warmup_1iter", lambda: e.train(max_iter=1, max_blocks=args.max_blocks, mode=args.mode))
     rows0 = float(e.state[4].item())
-    losses = timed("train", lambda: e.train(max_iter=args.iters, max_blocks=args.max_blocks))
+    losses = timed("train", lambda: e.train(max_iter=args.iters, max_blocks=args.max_blocks, mode=args.mode))
     rows = float(e.state[4].item())
     per = out["train_s"] / len(losses)
-    out["train"] = {"iterations": len(losses), "seconds_per_iteration": per, "losses": losses, "lam": e.lam,
+    out["train"] = {"iterations": len(losses), "seconds_per_iteration": per, "losses": losses, "lam": e.lam, "mode": e.mode_used,
                     "rows_per_iteration": rows / len(losses),
                     "algorithmic_GBps": rows / len(losses) * e.dim * 8 / per / 1e9,
                     "frac_of_8TBps": rows / len(losses) * e.dim * 8 / per / 8e12,
                     "ratings_per_s": g.n_ratings / per}
+    if args.split:
+        first = e.first.clone()
+        e.first.zero_()
+        rows0 = float(e.state[4].item())
+        timed("train_kl_only", lambda: e.train(max_iter=args.iters, max_blocks=args.max_blocks, first_iteration=100))
+        r1 = float(e.state[4].item()) - rows0
+        out["kl_only"] = {"seconds_per_iteration": out["train_kl_only_s"] / args.iters, "rows_per_iteration": r1 / args.iters,
+                          "algorithmic_GBps": r1 / args.iters * e.dim * 8 / (out["train_kl_only_s"] / args.iters) / 1e9}
+        e.first.copy_(first)
+        for md in ("atomic", "store"):
+            timed("train_mode_%s" % md, lambda: e.train(max_iter=2, mode=md, first_iteration=200))
     print(json.dumps(out))
 
 
