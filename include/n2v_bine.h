@@ -99,9 +99,11 @@ int n2v_bine_init(double* emb, double* ctx, int64_t n, int32_t dim, int32_t row_
  * Occurrence index: occ_ptr int64[n+1], occ_pos int64[n_tokens] (token positions of each vertex,
  * ascending), tokens int32[n_tokens], tok_walk int32[n_tokens] (walk of each token), walk_off
  * int64[n_walks+1]; both sides in one token array (walks of users, then walks of items).
- * state: double[8] = {lam, loss, last_loss, stop, rows, -, work counter (uint64 bits), -}; the pass adds its loss
+ * state: double[8] = {lam, loss, last_loss, stop, rows, rows_ref, work counter (uint64 bits), -}; the pass adds its loss
  * to state[1] and the number of embedding rows it read + wrote (algorithmic traffic = rows * dim * 8 B) to
- * state[4]; state[6] hands out chunks of ratings to the wavefronts and must be 0 on entry
+ * state[4], and to state[5] the rows the reference's access pattern moves for the same work (every
+ * skip_gram call reads and writes its context row and all target rows; a KL update 4 rows);
+ * state[6] hands out chunks of ratings to the wavefronts and must be 0 on entry
  * (n2v_bine_lambda_step resets it).
  * mode N2V_BINE_SEQUENTIAL: one wavefront walks the list in order with plain loads/stores — the
  * reference's exact update order (used for parity tests, small inputs).  N2V_BINE_PARALLEL:

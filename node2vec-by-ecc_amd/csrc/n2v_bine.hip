@@ -428,7 +428,7 @@ __device__ __forceinline__ uint32_t floyd_sample(uint32_t n, uint32_t m, int lan
 // skip_gram(c, z, negs) for every context z.  Returns nothing; adds to `loss` in the reference's order.
 template <int VPL, int NT, int MODE>
 __device__ __forceinline__ void node_block(const TrainArgs& a, int32_t c, double pa, double lam, int lane, double& loss,
-                                           uint32_t& rows, double* th0) {
+                                           uint32_t& rows, uint32_t& rows_ref, double* th0) {
     const double pl = pa * lam;
     const int64_t ob = uni64(a.occ_ptr[c]);
     const uint32_t n_occ = (uint32_t)uni((int32_t)(a.occ_ptr[c + 1] - ob));
@@ -572,6 +572,7 @@ __device__ __forceinline__ void node_block(const TrainArgs& a, int32_t c, double
             commit_row<VPL, MODE>(a.emb, z, stride, lane, nowV, upd);
             loss += l;
             rows += 2u;
+            rows_ref += 2u + 2u * (uint32_t)nt;  // skip_gram as written: V and every target row read and written per call
             if (todo && !fetched) Vn = load_row<VPL, MODE>(a.emb, zn, stride, lane);
         }
 #pragma unroll
@@ -607,7 +608,8 @@ bine_train_kernel(TrainArgs a) {
     const double gl = a.gamma * lam;
     const int stride = a.row_stride;
     double loss = 0.0;
-    uint32_t rows = 0;  // embedding rows read + written by this wave (algorithmic traffic, state[4])
+    uint32_t rows = 0;      // embedding rows this wave read + wrote (state[4])
+    uint32_t rows_ref = 0;  // rows the reference's access pattern would move for the same work (state[5])
     // Work is handed out in chunks of kChunk consecutive ratings through a counter in state[6]: the cost of a
     // rating varies by orders of magnitude (first-seen vertices carry their skip-gram block, and those cluster
     // at the head of the list and at regular strides), so any static assignment leaves most waves idle.
@@ -634,7 +636,7 @@ bine_train_kernel(TrainArgs a) {
                 held_u = -1;
             }
             for (int side = 0; side < 2; ++side)  // the user's block, then the item's (src/bine_train.py:462,475)
-                if (f & (1 << side)) node_block<VPL, NT, MODE>(a, side ? v : u, side ? a.beta : a.alpha, lam, lane, loss, rows, th0);
+                if (f & (1 << side)) node_block<VPL, NT, MODE>(a, side ? v : u, side ? a.beta : a.alpha, lam, lane, loss, rows, rows_ref, th0);
             // KL_divergence (src/bine_train.py:277-309)
             if (u != held_u) {
                 if (held_u >= 0) commit_row<VPL, MODE>(a.emb, held_u, stride, lane, U, dU);
@@ -660,12 +662,14 @@ bine_train_kernel(TrainArgs a) {
             commit_row<VPL, MODE>(a.emb, v, stride, lane, nv, dv);
             loss += a.gamma * w * log(sig);
             rows += 2u;
+            rows_ref += 4u;
         }
         if (held_u >= 0) commit_row<VPL, MODE>(a.emb, held_u, stride, lane, U, dU);
     }
     if (lane == 0) {
         __hip_atomic_fetch_add(&a.state[1], loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&a.state[4], (double)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.state[5], (double)rows_ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

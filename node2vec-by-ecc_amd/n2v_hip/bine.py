@@ -264,12 +264,7 @@ class BineEngine:
                                               self._seed(SEED_INIT), self._stream()))
         return self
 
-    def train(self, max_iter=50, alpha=0.01, beta=0.01, gamma=0.1, lam=0.01, ws=5, ns=4, epsilon=1e-3,
-              mode="parallel", max_blocks=0, e_range=None, first_iteration=0):
-        """The iteration loop of src/bine_train.py:452-504.  mode='sequential' reproduces the reference's update
-        order with one wavefront (parity tests); 'atomic' / 'store' are the two parallel variants of
-        include/n2v_bine.h, 'parallel' picks between them by graph size.  Returns the per-iteration
-        losses; `self.lam` is the final learning rate."""
+    def _prepare(self, mode):
         if self.emb is None:
             self.init_embeddings()
         if self.pool is None:
@@ -278,33 +273,65 @@ class BineEngine:
             self.build_occurrences()
         if mode == "parallel":   # like the SGNS row-sharing policy: lossless atomics while every row is hot
             mode = "atomic" if self.g.n < AUTO_STORE_MIN_VERTICES else "store"
-        md = {"sequential": _lib.BINE_SEQUENTIAL, "atomic": _lib.BINE_PARALLEL, "store": _lib.BINE_PARALLEL_STORE}[mode]
         self.mode_used = mode
-        lib, p = self.lib, _lib.ptr
+        return {"sequential": _lib.BINE_SEQUENTIAL, "atomic": _lib.BINE_PARALLEL, "store": _lib.BINE_PARALLEL_STORE}[mode]
+
+    def reset_schedule(self, lam=0.01):
+        """Start of `train`: learning rate lam, last_loss = 0 (src/bine_train.py:434,452)."""
+        self.state.copy_(torch.tensor([lam, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float64))
+        self.losses = []
+
+    def train_pass(self, iteration, alpha=0.01, beta=0.01, gamma=0.1, ws=5, ns=4, mode="parallel", max_blocks=0,
+                   e_range=None):
+        """One pass over the rating list (or this rank's range of it): src/bine_train.py:461-494."""
+        md = self._prepare(mode)
+        p = _lib.ptr
         e0, e1 = e_range if e_range is not None else (0, self.g.n_ratings)
         with torch.cuda.device(self.device):
-            if first_iteration == 0:
-                self.state.copy_(torch.tensor([lam, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float64))
-                self.losses = []
-            for it in range(first_iteration, first_iteration + max_iter):
-                _lib.check(lib.n2v_bine_train_pass(
-                    p(self.edge_u), p(self.edge_v), p(self.edge_w), p(self.first), e0, e1, p(self.emb), p(self.ctx),
-                    self.dim, self.stride, p(self.occ_ptr), p(self.occ_pos), p(self.tokens), p(self.tok_walk),
-                    p(self.walk_off), p(self.pool), int(self.pool.shape[1]), int(ws), int(ns), float(alpha), float(beta),
-                    float(gamma), p(self.state), it, self._seed(SEED_OCC), self._seed(SEED_NEG), md, int(max_blocks),
-                    self._stream()))
-                if self.pre_lambda_hook is not None:
-                    self.pre_lambda_hook(self)
-                loss_now = self.state[1:2].clone()
-                _lib.check(lib.n2v_bine_lambda_step(p(self.state), float(epsilon), self._stream()))
-                st = self.state.tolist()
-                self.losses.append(float(loss_now.item()))
-                if st[3] != 0.0:
-                    break
-            self.lam = float(self.state[0].item())
+            _lib.check(self.lib.n2v_bine_train_pass(
+                p(self.edge_u), p(self.edge_v), p(self.edge_w), p(self.first), e0, e1, p(self.emb), p(self.ctx),
+                self.dim, self.stride, p(self.occ_ptr), p(self.occ_pos), p(self.tokens), p(self.tok_walk),
+                p(self.walk_off), p(self.pool), int(self.pool.shape[1]), int(ws), int(ns), float(alpha), float(beta),
+                float(gamma), p(self.state), int(iteration), self._seed(SEED_OCC), self._seed(SEED_NEG), md,
+                int(max_blocks), self._stream()))
+
+    def finish_iteration(self, epsilon=1e-3):
+        """src/bine_train.py:495-502: learning-rate step on the pass's loss; returns (loss, stop)."""
+        with torch.cuda.device(self.device):
+            loss_now = self.state[1:2].clone()
+            _lib.check(self.lib.n2v_bine_lambda_step(_lib.ptr(self.state), float(epsilon), self._stream()))
+            stop = self.state[3].item() != 0.0
+        self.losses.append(float(loss_now.item()))
+        return self.losses[-1], stop
+
+    def train(self, max_iter=50, alpha=0.01, beta=0.01, gamma=0.1, lam=0.01, ws=5, ns=4, epsilon=1e-3,
+              mode="parallel", max_blocks=0, e_range=None, first_iteration=0, merge=None):
+        """The iteration loop of src/bine_train.py:452-504.  mode='sequential' reproduces the reference's update
+        order with one wavefront (parity tests); 'atomic' / 'store' are the two parallel variants of
+        include/n2v_bine.h, 'parallel' picks between them by graph size.  `merge(engine)` runs between a pass and
+        its learning-rate step (multi-GPU: ReplicaMerge).  Returns the per-iteration losses; `self.lam` is the
+        final learning rate."""
+        self._prepare(mode)
+        if first_iteration == 0:
+            self.reset_schedule(lam)
+        for it in range(first_iteration, first_iteration + max_iter):
+            self.train_pass(it, alpha, beta, gamma, ws, ns, mode, max_blocks, e_range)
+            if merge is not None:
+                merge(self)
+            if self.finish_iteration(epsilon)[1]:
+                break
+        self.lam = float(self.state[0].item())
         return self.losses
 
-    pre_lambda_hook = None  # multi-GPU: merge replicas and all-reduce the loss before the learning-rate step
+    def train_sharded(self, comm, rank, world, **kw):
+        """One process per GPU (BASELINE config 5 on 8 GPUs): every rank holds the whole graph, walks, pools and
+        a replica of both tables (all derived from the same seeds, so identical without communication), passes
+        over its contiguous range of the rating list, and the replicas' changes are summed over RCCL before the
+        learning-rate step — every rank then holds what one shared table would have received."""
+        per = -(-self.g.n_ratings // world)
+        e0 = min(rank * per, self.g.n_ratings)
+        self._prepare(kw.get("mode", "parallel"))
+        return self.train(e_range=(e0, min(e0 + per, self.g.n_ratings)), merge=ReplicaMerge(self, comm), **kw)
 
     # ------------------------------------------------------------------ results
     def vectors(self, side, which="embedding"):
@@ -312,3 +339,23 @@ class BineEngine:
         t = self.emb if which == "embedding" else self.ctx
         lo, hi = (0, self.g.n_u) if side == "u" else (self.g.n_u, self.g.n)
         return t[lo:hi, : self.dim].cpu().numpy()
+
+
+class ReplicaMerge:
+    """Sum of the replicas' changes since the last merge, applied to every replica; the pass's loss (and the
+    traffic counters) are summed too, so the learning-rate rule sees the whole list's loss.  `comm` needs
+    all_reduce_sum(tensor) (n2v_hip.dist._Comm over RCCL, or gloo in rehearsals)."""
+
+    def __init__(self, engine, comm):
+        self.comm = comm
+        self.base = [engine.emb.clone(), engine.ctx.clone()]
+
+    def __call__(self, engine):
+        for t, base in zip((engine.emb, engine.ctx), self.base):
+            t.sub_(base)
+            self.comm.all_reduce_sum(t)
+            t.add_(base)
+            base.copy_(t)
+        part = engine.state[1:2].clone()
+        self.comm.all_reduce_sum(part)
+        engine.state[1:2].copy_(part)

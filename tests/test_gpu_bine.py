@@ -168,3 +168,77 @@ def test_vectors_accessor_and_walk_lists(eng):
     assert vu.shape == (eng.g.n_u, 32) and vv.shape == (eng.g.n_v, 32)
     wl = eng.walks_as_lists("v")
     assert len(wl) == eng.n_walks[1] and all(str(x).startswith("i") for x in wl[0])
+
+
+def test_replica_merge_matches_single_table_run():
+    """Multi-GPU scheme (BineEngine.train_sharded) with the replicas simulated in one process: two engines with
+    identical state pass over the two halves of the rating list, the sum of their changes is applied to both —
+    the loss trajectory follows the single-table run."""
+    from n2v_hip import bine
+    g = make_graph(seed=11, n_u=400, n_v=150, per_user=6)
+
+    def fresh():
+        e = bine.BineEngine(g, device="cuda:0", seed=5)
+        e.calculate_centrality()
+        e.generate_walks(maxT=6)
+        e.build_negative_pools(pool_size=16, max_jaccard=0.1)
+        e.build_occurrences()
+        e.init_embeddings(d=48)
+        return e
+
+    single = fresh()
+    want = single.train(max_iter=5, mode="atomic")
+    reps = [fresh(), fresh()]
+    assert torch_equal(reps[0].emb, reps[1].emb) and torch_equal(reps[0].tokens, single.tokens)
+    half = g.n_ratings // 2
+    ranges = [(0, half), (half, g.n_ratings)]
+    for r in reps:
+        r.reset_schedule(0.01)
+    bases = [reps[0].emb.clone(), reps[0].ctx.clone()]
+    got = []
+    for it in range(5):
+        for r, rg in zip(reps, ranges):
+            r.train_pass(it, mode="atomic", e_range=rg)
+        for k, name in enumerate(("emb", "ctx")):
+            total = bases[k] + sum(getattr(r, name) - bases[k] for r in reps)
+            for r in reps:
+                getattr(r, name).copy_(total)
+            bases[k] = total.clone()
+        loss = sum(r.state[1] for r in reps)
+        for r in reps:
+            r.state[1] = loss
+            got.append(r.finish_iteration()[0])
+    assert np.allclose(got[0::2], got[1::2], rtol=0, atol=0)        # replicas stay in lockstep
+    assert np.allclose(got[0::2], want, rtol=5e-3)
+    assert reps[0].state[0].item() == single.state[0].item()       # same learning-rate decisions
+
+
+def torch_equal(a, b):
+    import torch
+    return bool(torch.equal(a, b))
+
+
+def test_two_rank_probe_over_gloo(tmp_path):
+    """Two ranks of tools/bine_probe.py under torch.distributed.run sharing the one GPU (merges over gloo through
+    host memory — the rehearsal path of n2v_hip.dist; on a multi-GPU node the same code runs over RCCL)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = 29300 + os.getpid() % 300
+    base = [os.path.join(ROOT, "tools", "bine_probe.py"), "--users", "3000", "--items", "2000", "--ratings", "60000",
+            "--dim", "64", "--iters", "4", "--maxT", "8", "--pool", "32", "--mode", "atomic"]
+    one = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + ["--backend", "gloo"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    j2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert j2["n_gpus"] == 2 and j1["walks"] == j2["walks"]
+    assert np.allclose(j1["train"]["losses"], j2["train"]["losses"], rtol=5e-3)

@@ -28,20 +28,27 @@ def main():
     ap.add_argument("--pool", type=int, default=200)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--mode", default="parallel", choices=["parallel", "atomic", "store"])
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     ap.add_argument("--split", action="store_true", help="also time a pass with the skip-gram blocks disabled (KL only)")
     args = ap.parse_args()
     from n2v_hip import bine, synth
+    from n2v_hip import dist as n2v_dist
+    ctx = n2v_dist.RankContext(backend=args.backend)   # one process per GPU under torch.distributed.run
+    dev = str(ctx.device)
 
-    out = {"config": vars(args)}
+    out = {"config": vars(args), "n_gpus": ctx.world}
     sync = torch.cuda.synchronize
 
     def timed(name, fn):
         sync()
+        ctx.barrier()
         t0 = time.perf_counter()
         r = fn()
         sync()
+        ctx.barrier()
         out[name + "_s"] = time.perf_counter() - t0
-        print("[bine] %-22s %.3f s" % (name, out[name + "_s"]), file=sys.stderr, flush=True)
+        if ctx.rank == 0:
+            print("[bine] %-22s %.3f s" % (name, out[name + "_s"]), file=sys.stderr, flush=True)
         return r
 
     t0 = time.perf_counter()
@@ -51,8 +58,15 @@ def main():
     deg = np.diff(g.row_ptr)
     out["graph"] = {"n_u": g.n_u, "n_v": g.n_v, "ratings": g.n_ratings, "nnz": int(g.col.shape[0]),
                     "max_deg_u": int(deg[: g.n_u].max()), "max_deg_v": int(deg[g.n_u:].max())}
-    print("[bine] graph", out["graph"], "%.1f s" % out["host_graph_s"], file=sys.stderr, flush=True)
-    e = timed("upload", lambda: bine.BineEngine(g, device="cuda:0", seed=42))
+    if ctx.rank == 0:
+        print("[bine] graph", out["graph"], "%.1f s" % out["host_graph_s"], file=sys.stderr, flush=True)
+    e = timed("upload", lambda: bine.BineEngine(g, device=dev, seed=42))
+
+    def run(**kw):
+        if ctx.world > 1:
+            return e.train_sharded(ctx.comm, ctx.rank, ctx.world, **kw)
+        return e.train(**kw)
+
     timed("hits", e.calculate_centrality)
     out["hits_iterations"] = e.hits_iterations
     timed("walks", lambda: e.generate_walks(0.15, args.maxT, 1))
@@ -60,17 +74,18 @@ def main():
     timed("neg_pools", lambda: e.build_negative_pools(args.pool))
     timed("occurrences", e.build_occurrences)
     timed("init", lambda: e.init_embeddings(args.dim))
-    timed("train_warmup_1iter", lambda: e.train(max_iter=1, max_blocks=args.max_blocks, mode=args.mode))
-    rows0 = float(e.state[4].item())
-    losses = timed("train", lambda: e.train(max_iter=args.iters, max_blocks=args.max_blocks, mode=args.mode))
-    rows = float(e.state[4].item())
+    timed("train_warmup_1iter", lambda: run(max_iter=1, max_blocks=args.max_blocks, mode=args.mode))
+    losses = timed("train", lambda: run(max_iter=args.iters, max_blocks=args.max_blocks, mode=args.mode))
+    rows, rows_ref = float(e.state[4].item()), float(e.state[5].item())
     per = out["train_s"] / len(losses)
     out["train"] = {"iterations": len(losses), "seconds_per_iteration": per, "losses": losses, "lam": e.lam, "mode": e.mode_used,
                     "rows_per_iteration": rows / len(losses),
                     "algorithmic_GBps": rows / len(losses) * e.dim * 8 / per / 1e9,
                     "frac_of_8TBps": rows / len(losses) * e.dim * 8 / per / 8e12,
+                    "reference_pattern_rows_per_iteration": rows_ref / len(losses),
+                    "reference_pattern_GBps": rows_ref / len(losses) * e.dim * 8 / per / 1e9,
                     "ratings_per_s": g.n_ratings / per}
-    if args.split:
+    if args.split and ctx.world == 1:
         first = e.first.clone()
         e.first.zero_()
         rows0 = float(e.state[4].item())
@@ -81,7 +96,9 @@ def main():
         e.first.copy_(first)
         for md in ("atomic", "store"):
             timed("train_mode_%s" % md, lambda: e.train(max_iter=2, mode=md, first_iteration=200))
-    print(json.dumps(out))
+    if ctx.rank == 0:
+        print(json.dumps(out))
+    ctx.close()
 
 
 if __name__ == "__main__":
