@@ -34,6 +34,8 @@ CONFIGS = {
     # name: (graph key, p, q, description)
     "C2": ("C2", 1.0, 1.0, "C2: Erdos-Renyi 100k nodes / 1M edges, p=q=1, d=128"),
     "C3": ("C3", 0.25, 4.0, "C3: power-law (Barabasi-Albert) 1M nodes / 10M edges, p=0.25 q=4, d=128"),
+    # BASELINE config 5 (BiNE path): its own pipeline and JSON line, see bench_bine()
+    "C5": ("C5", None, None, "C5: bipartite 500k users + 500k items / 20M ratings, item popularity power-law, BiNE d=256"),
 }
 
 
@@ -96,6 +98,84 @@ def cpu_baselines(cg, p, q, walks_sample, lens_sample, counts, dim, budget_s=12.
     return out
 
 
+def bench_bine(args):
+    """`--config C5`: the BiNE path (src/bine_train.py) at BASELINE config 5.  A step = one training iteration:
+    one pass over the 20M-rating list (skip-gram blocks of first-seen vertices + the KL update per rating), the
+    replica merge when N > 1 (RCCL all-reduce of both tables) and the learning-rate step.  Strong scaling: the
+    rating list is split among the ranks.  HITS, walks, pools and the occurrence index are built before the
+    timed region (reported under "stages")."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bine_probe
+    from n2v_hip import dist as n2v_dist
+    ctx = n2v_dist.RankContext(backend=args.backend)
+    pa = bine_probe.parser().parse_args([])
+    pa.dim = args.dim if args.dim != 128 else 256
+    pa.iters, pa.warmup_iters, pa.backend = args.steps, max(1, args.warmup), args.backend
+    out = bine_probe.run(pa, ctx=ctx, emit=False)
+    e, tr = out.pop("engine"), out["train"]
+    if ctx.rank != 0:
+        ctx.close()
+        return
+    K = tr["iterations"]
+    launch_s = out["train_event_s"] / K
+    bytes_launch = tr["rows_per_iteration"] * e.dim * 8
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("C5_n1") if ctx.world == 1 else None
+    except Exception:
+        traffic = None
+    result = {
+        "metric": "BiNE rating-updates/s", "value": out["graph"]["ratings"] * K / out["train_s"],
+        "unit": "rating-updates/s", "n_gpus": ctx.world, "steps": K, "warmup": pa.warmup_iters,
+        "ms_per_step": out["train_s"] / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": CONFIGS["C5"][3], "ws": 5, "ns": 4, "maxT": pa.maxT, "minT": 1, "stop_probability": 0.15,
+                   "dim": e.dim, "row_sharing": e.mode_used, **out["graph"], **out["walks"],
+                   "sharding": "rating list split among ranks, replicas' changes summed over RCCL every iteration"
+                   if ctx.world > 1 else "single GPU"},
+        "stages_seconds": {k[:-2]: v for k, v in out.items() if k.endswith("_s") and not k.startswith("train")},
+        "hits_iterations": out["hits_iterations"], "losses": tr["losses"][-K:],
+        "roofline": {"kernel": "bine_train_kernel", "bound": "hbm", "achieved": bytes_launch / launch_s / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / launch_s / 1e9 / HBM_PEAK_GBS,
+                     "traffic": (traffic or {}).get("bine_train_kernel"),
+                     "algorithmic_bytes_per_unit": bytes_launch / out["graph"]["ratings"], "unit_name": "rating",
+                     "units_per_launch": out["graph"]["ratings"] // ctx.world, "launch_ms": launch_s * 1e3,
+                     "accounting": "rows the kernel reads + writes (counted by the kernel) x dim x 8 B; the reference's "
+                                   "own access pattern (every skip_gram call re-reads and re-writes all its rows) "
+                                   "would move %.3g B per launch" % (tr["reference_pattern_rows_per_iteration"] * e.dim * 8)},
+    }
+    if not args.no_cpu_baseline and ctx.world == 1:
+        result["cpu_baseline"] = bine_cpu_baseline(e)
+    print(json.dumps(result), flush=True)
+    ctx.close()
+
+
+def bine_cpu_baseline(e, budget_s=15.0):
+    """numpy restatement of src/bine_train.py:243-309,461-494 (oracle/bine_oracle.py) on every k-th rating of the
+    same list with its real first-visit flags, against copies of the device's tables."""
+    from n2v_hip import bine
+    from oracle import bine_oracle as bo
+    g = e.g
+    host = {k: getattr(e, k).cpu().numpy() for k in ("occ_ptr", "occ_pos", "tokens", "tok_walk", "walk_off", "pool")}
+    emb = e.emb[:, : e.dim].cpu().numpy().copy()
+    ctx_t = e.ctx[:, : e.dim].cpu().numpy().copy()
+    stride = max(1, g.n_ratings // 40000)
+    idx = np.arange(0, g.n_ratings, stride)
+    done, t0 = 0, time.perf_counter()
+    for b in range(0, len(idx), 500):
+        sel = idx[b:b + 500]
+        bo.train(g.edge_u[sel], g.edge_v[sel], g.edge_w[sel], emb, ctx_t, host["occ_ptr"], host["occ_pos"], host["tokens"],
+                 host["tok_walk"], host["walk_off"], host["pool"], 5, 4, 0.01, 0.01, 0.1, 0.01, 1,
+                 bine.derive_seed(e.seed, bine.SEED_OCC), bine.derive_seed(e.seed, bine.SEED_NEG), first=g.first[sel])
+        done += len(sel)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "rating-updates/s", "cores": 1, "kind": "port",
+            "sample": "every %d-th rating of the same list (%d ratings, with their first-visit flags), one iteration; "
+                      "numpy restatement of skip_gram / KL_divergence / the train loop; %.1f s" % (stride, done, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +200,8 @@ def main():
         args.gpus = world
     if torch.cuda.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback)")
+    if args.config == "C5":
+        return bench_bine(args)
     import node2vec
     from n2v_hip import dist as n2v_dist
     from n2v_hip import sgns, synth

@@ -261,10 +261,11 @@ def kl_divergence(e_ij, u, v, emb, lam, gamma):
 
 
 def train(edge_u, edge_v, edge_w, emb, ctx, occ_ptr, occ_pos, tokens, tok_walk, walk_off, pool, ws, ns, alpha, beta,
-          gamma, lam, max_iter, seed_occ, seed_neg, epsilon=1e-3):
+          gamma, lam, max_iter, seed_occ, seed_neg, epsilon=1e-3, first=None):
     """The loop of src/bine_train.py:452-504 over the rating list, with the device's sampling rule for the
     occurrences / negatives (the reference uses the global `random`).  emb, ctx: float64 [N, d], updated in
-    place.  Returns (lam, per-iteration losses)."""
+    place.  `first` (optional, uint8 per rating: bit 0 user, bit 1 item) replaces the visited dictionaries when
+    only a sample of the rating list is passed.  Returns (lam, per-iteration losses)."""
     last_loss = 0.0
     losses = []
     for it in range(max_iter):
@@ -272,8 +273,11 @@ def train(edge_u, edge_v, edge_w, emb, ctx, occ_ptr, occ_pos, tokens, tok_walk, 
         seen = set()
         for e in range(len(edge_u)):
             u, v, w = int(edge_u[e]), int(edge_v[e]), float(edge_w[e])
-            for c, pa in ((u, alpha), (v, beta)):
-                if c in seen:
+            for side, (c, pa) in enumerate(((u, alpha), (v, beta))):
+                if first is not None:
+                    if not (int(first[e]) >> side) & 1:
+                        continue
+                elif c in seen:
                     continue
                 seen.add(c)
                 ob = int(occ_ptr[c])

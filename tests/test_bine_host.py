@@ -154,3 +154,67 @@ def test_training_restatement_runs_and_steps_lambda():
     assert lam == want
     e0, _ = bo.init_rows(g.n, 8, 5)
     assert np.abs(emb - e0).max() > 1e-4
+
+
+_GLOO_WORKER = r'''
+import os, sys, types
+sys.path.insert(0, os.path.join(%(root)r, "node2vec-by-ecc_amd"))
+import torch, torch.distributed as dist
+from n2v_hip import bine, sgns
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+comm = sgns._ProcessGroupComm()
+base = torch.arange(24, dtype=torch.float64).reshape(4, 6)
+eng = types.SimpleNamespace(emb=base.clone(), ctx=-base.clone(), state=torch.zeros(8, dtype=torch.float64))
+merge = bine.ReplicaMerge(eng, comm)
+for step in range(2):
+    eng.emb[rank] += 1.0 + rank          # each replica changes its own row ...
+    eng.emb[3] += 10.0 * (rank + 1)      # ... and both change row 3
+    eng.ctx[2] -= 0.5
+    eng.state[1] = -(3.0 + rank)         # this replica's part of the loss
+    merge(eng)
+    want = base.clone(); want[0] += 1.0 * (step + 1); want[1] += 2.0 * (step + 1); want[3] += 30.0 * (step + 1)
+    assert torch.equal(eng.emb, want), (eng.emb, want)
+    wc = -base.clone(); wc[2] -= 1.0 * (step + 1)
+    assert torch.equal(eng.ctx, wc)
+    assert eng.state[1].item() == -7.0
+    assert torch.equal(merge.base[0], eng.emb) and torch.equal(merge.base[1], eng.ctx)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_bine_replica_merge_over_gloo_world2(tmp_path):
+    import subprocess
+    port = 31500 + (os.getpid() % 2000)
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER % {"root": ROOT, "port": port})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+def test_recommendation_metrics_match_the_reference_formulas():
+    """top_N's metric helpers (src/bine_train.py:361-406) on a hand-checked case."""
+    import bine_train as bt
+    ranked, truth = ["a", "b", "c", "d"], ["b", "d", "x"]
+    assert bt.precision_and_racall(ranked, truth) == (0.5, 2 / 3)
+    assert bt.AP(ranked, truth) == pytest.approx((1 / 2 + 2 / 4) / 3)
+    assert bt.RR(ranked, truth) == 0.5
+    idcg = 1 / math.log(2, 2) + 1 / math.log(3, 2) + 1 / math.log(4, 2)
+    assert bt.nDCG(ranked, truth) == pytest.approx((1 / math.log(3, 2) + 1 / math.log(5, 2)) / idcg)
+    assert bt.ndarray_tostring(np.array([[0.5, 1.0]])) == "0.5 1.0 \n"
+    a = bt.default_args(d=64)
+    assert (a.ws, a.ns, a.maxT, a.minT, a.p, a.alpha, a.beta, a.gamma, a.lam, a.max_iter, a.d) == \
+        (5, 4, 32, 1, 0.15, 0.01, 0.01, 0.1, 0.01, 50, 64)
+
+
+def test_bine_engine_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from n2v_hip import bine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        bine.BineEngine(small_graph())

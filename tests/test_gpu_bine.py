@@ -242,3 +242,52 @@ def test_two_rank_probe_over_gloo(tmp_path):
     j2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert j2["n_gpus"] == 2 and j1["walks"] == j2["walks"]
     assert np.allclose(j1["train"]["losses"], j2["train"]["losses"], rtol=5e-3)
+
+
+def test_drop_in_train_flow(tmp_path):
+    """The reference's call sequence (src/bine_train.py:600-612): GraphUtils -> construct_training_graph ->
+    train(args, gul); vectors_u.dat / vectors_v.dat in its text format; top_N on held-out ratings."""
+    import bine_train as bt
+    rs = np.random.RandomState(1)
+    lines, test_rate = [], {}
+    for u in range(120):
+        liked = rs.choice(40, size=8, replace=False) if u % 2 else rs.choice(np.arange(40, 80), size=8, replace=False)
+        for k, i in enumerate(liked):
+            if k == 0:
+                test_rate.setdefault("u%d" % u, {})["i%d" % i] = 5.0      # held out
+            else:
+                lines.append("u%d\ti%d\t%d\n" % (u, i, rs.randint(3, 6)))
+        if u % 3 == 0:   # a few shared blockbusters keep the graph connected (HITS needs a spectral gap)
+            lines.append("u%d\ti%d\t%d\n" % (u, 100 + u % 2, 4))
+            lines.append("u%d\ti%d\t%d\n" % (u, 20 + 40 * ((u // 3) % 2), 3))
+    f = tmp_path / "ratings_train.dat"
+    f.write_text("".join(lines))
+    gul = bt.GraphUtils(str(tmp_path), device="cuda:0", seed=3)
+    gul.construct_training_graph(str(f))
+    items = sorted({i for d in test_rate.values() for i in d} & set(gul.node_v))
+    test_rate = {u: {i: r for i, r in d.items() if i in items} for u, d in test_rate.items()}
+    test_rate = {u: d for u, d in test_rate.items() if d and u in set(gul.node_u)}
+    args = bt.default_args(d=32, max_iter=30, maxT=8, model_path=str(tmp_path), save=True,
+                           test_rates=(list(test_rate), items, test_rate))
+    node_list_u, roc, ap = bt.train(args, gul)
+    assert (roc, ap) == (0, 0) and len(node_list_u) == len(gul.node_u)
+    assert node_list_u["u7"]["embedding_vectors"].shape == (1, 32)
+    rows = (tmp_path / "vectors_u.dat").read_text().splitlines()
+    assert len(rows) == len(gul.node_u) and rows[0].split()[0] == gul.node_u[0] and len(rows[0].split()) == 33
+    assert np.allclose([float(x) for x in rows[0].split()[1:]], node_list_u[gul.node_u[0]]["embedding_vectors"][0])
+    assert len((tmp_path / "vectors_v.dat").read_text().splitlines()) == len(gul.node_v)
+    f1, m_ap, mrr, ndcg = bt.train.last["metrics"]
+    assert 0 <= f1 <= 1 and 0 <= m_ap <= 1 and 0 <= mrr <= 1 and 0 <= ndcg <= 1
+    assert len(bt.train.last["losses"]) >= 1 and gul.authority_u and len(gul.walks_u) == gul.engine.n_walks[0]
+    assert gul.edge_list[0] == ("u0", lines[0].split("\t")[1], float(lines[0].split("\t")[2]))
+
+
+def test_hits_raises_like_networkx_when_it_does_not_converge():
+    """networkx 1.11 raises after max_iter power iterations; two equal disconnected halves never separate."""
+    from n2v_hip import bine
+    users = ["u%d" % (k // 2) for k in range(40)]
+    items = ["i%d" % (2 * (k // 20) + k % 2) for k in range(40)]      # users 0-9 on items 0/1, users 10-19 on items 2/3
+    w = [1.0 + (k // 20) * 1e-9 for k in range(40)]
+    e = bine.BineEngine(bine.BipartiteGraph(users, items, w), device="cuda:0")
+    with pytest.raises(bine.BineConvergenceError):
+        e.calculate_centrality(max_iter=5, tol=1e-30)

@@ -17,23 +17,30 @@ import numpy as np
 import torch
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--users", type=int, default=500_000)
     ap.add_argument("--items", type=int, default=500_000)
     ap.add_argument("--ratings", type=int, default=20_000_000)
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--warmup-iters", type=int, default=1)
     ap.add_argument("--maxT", type=int, default=32)
     ap.add_argument("--pool", type=int, default=200)
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--mode", default="parallel", choices=["parallel", "atomic", "store"])
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     ap.add_argument("--split", action="store_true", help="also time a pass with the skip-gram blocks disabled (KL only)")
-    args = ap.parse_args()
+    return ap
+
+
+def run(args, ctx=None, emit=True):
+    """The whole BiNE pipeline once, timed per stage; returns the result dict (rank 0 prints it when emit)."""
     from n2v_hip import bine, synth
     from n2v_hip import dist as n2v_dist
-    ctx = n2v_dist.RankContext(backend=args.backend)   # one process per GPU under torch.distributed.run
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = n2v_dist.RankContext(backend=args.backend)   # one process per GPU under torch.distributed.run
     dev = str(ctx.device)
 
     out = {"config": vars(args), "n_gpus": ctx.world}
@@ -74,8 +81,13 @@ def main():
     timed("neg_pools", lambda: e.build_negative_pools(args.pool))
     timed("occurrences", e.build_occurrences)
     timed("init", lambda: e.init_embeddings(args.dim))
-    timed("train_warmup_1iter", lambda: run(max_iter=1, max_blocks=args.max_blocks, mode=args.mode))
+    timed("train_warmup", lambda: run(max_iter=max(1, args.warmup_iters), max_blocks=args.max_blocks, mode=args.mode))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     losses = timed("train", lambda: run(max_iter=args.iters, max_blocks=args.max_blocks, mode=args.mode))
+    ev1.record()
+    sync()
+    out["train_event_s"] = ev0.elapsed_time(ev1) / 1e3
     rows, rows_ref = float(e.state[4].item()), float(e.state[5].item())
     per = out["train_s"] / len(losses)
     out["train"] = {"iterations": len(losses), "seconds_per_iteration": per, "losses": losses, "lam": e.lam, "mode": e.mode_used,
@@ -96,9 +108,16 @@ def main():
         e.first.copy_(first)
         for md in ("atomic", "store"):
             timed("train_mode_%s" % md, lambda: e.train(max_iter=2, mode=md, first_iteration=200))
-    if ctx.rank == 0:
-        print(json.dumps(out))
-    ctx.close()
+    out["engine"] = e
+    if emit and ctx.rank == 0:
+        print(json.dumps({k: v for k, v in out.items() if k != "engine"}))
+    if own_ctx:
+        ctx.close()
+    return out
+
+
+def main():
+    run(parser().parse_args())
 
 
 if __name__ == "__main__":
