@@ -38,6 +38,16 @@ class BineConvergenceError(RuntimeError):
     """networkx 1.11 raises NetworkXError when hits() does not converge in max_iter iterations."""
 
 
+def _unique_inverse(labels):
+    """np.unique(labels, return_inverse=True); integer labels of moderate range skip the sort."""
+    labels = np.asarray(labels)
+    if labels.dtype.kind in "iu" and labels.size and labels.min() >= 0 and labels.max() < 8 * labels.size + 1024:
+        present = np.bincount(labels) > 0
+        rank = np.cumsum(present) - 1
+        return np.nonzero(present)[0].astype(labels.dtype), rank[labels]
+    return np.unique(labels, return_inverse=True)
+
+
 class BipartiteGraph:
     """Host-side bipartite rating graph (src/bine_graph_utils.py:32-58).
 
@@ -52,8 +62,8 @@ class BipartiteGraph:
         ratings = np.asarray(ratings, dtype=np.float64)
         if not (len(users) == len(items) == len(ratings)):
             raise ValueError("users, items and ratings must have the same length")
-        self.user_labels, eu = np.unique(users, return_inverse=True)
-        self.item_labels, ev = np.unique(items, return_inverse=True)
+        self.user_labels, eu = _unique_inverse(users)
+        self.item_labels, ev = _unique_inverse(items)
         self.n_u, self.n_v = len(self.user_labels), len(self.item_labels)
         self.n = self.n_u + self.n_v
         E = len(eu)
@@ -65,26 +75,30 @@ class BipartiteGraph:
         last[:-1] = ks[1:] != ks[:-1]
         pair_key = ks[last]
         pair_w = ratings[order][last]
+        group = np.empty(E, dtype=np.int64)                  # index of each rating's pair in the distinct list
+        group[order] = np.cumsum(np.concatenate([[0], last[:-1]]))
         self.edge_u = eu.astype(np.int32)
         self.edge_v = (ev + self.n_u).astype(np.int32)
-        self.edge_w = pair_w[np.searchsorted(pair_key, key)]
+        self.edge_w = pair_w[group]
         # visited_u / visited_v (src/bine_train.py:458-487): a vertex is handled at its first rating
         first = np.zeros(E, dtype=np.uint8)
         if E:
-            first[np.unique(eu, return_index=True)[1]] |= 1
-            first[np.unique(ev, return_index=True)[1]] |= 2
+            back = np.arange(E - 1, -1, -1)
+            for ids, n_side, bit in ((eu, self.n_u, 1), (ev, self.n_v, 2)):
+                pos = np.empty(n_side, dtype=np.int64)
+                pos[ids[::-1]] = back                        # the last write per vertex is its smallest index
+                first[pos] |= bit
         self.first = first
-        # symmetric CSR over users + items
+        # symmetric CSR over users + items.  The distinct pairs are already ordered by (user, item): that IS the
+        # users' half; the items' half is the same list stably re-ordered by item (users stay ascending).
         pu = (pair_key // max(self.n_v, 1)).astype(np.int64)
-        pv = (pair_key % max(self.n_v, 1)).astype(np.int64) + self.n_u
-        src = np.concatenate([pu, pv])
-        dst = np.concatenate([pv, pu])
-        ww = np.concatenate([pair_w, pair_w])
-        o = np.lexsort((dst, src))
-        self.col = dst[o].astype(np.int32)
-        self.w = ww[o]
+        pv = (pair_key % max(self.n_v, 1)).astype(np.int64)
+        by_item = np.argsort(pv, kind="stable")
+        self.col = np.concatenate([pv + self.n_u, pu[by_item]]).astype(np.int32)
+        self.w = np.concatenate([pair_w, pair_w[by_item]])
         self.row_ptr = np.zeros(self.n + 1, dtype=np.int64)
-        np.cumsum(np.bincount(src, minlength=self.n), out=self.row_ptr[1:])
+        np.cumsum(np.concatenate([np.bincount(pu, minlength=self.n_u), np.bincount(pv, minlength=self.n_v)]),
+                  out=self.row_ptr[1:])
 
     @property
     def n_ratings(self):

@@ -65,6 +65,57 @@ def simulate(G, corpus, n_nodes, rounds, merge, syncs, mode="atomic"):
     return models[0]
 
 
+def simulate_tier(G, corpus, n_nodes, rounds, syncs, K, B=256.0, mode="atomic"):
+    """Two-tier merge: rows whose expected updates per full interval exceed the budget B (hubs, frequent
+    negatives) are merged K times per full interval (small message), all rows once per full interval.
+    Weights as merge 'hot', computed for the interval a row actually waited."""
+    n = corpus.walks.shape[0] // rounds
+    models = [sgns.SgnsModel(n_nodes, dim=128, window=10, negative=5, seed=1, update_mode=mode) for _ in range(G)]
+    counts = torch.bincount(corpus.walks.reshape(-1).long(), minlength=n_nodes)
+    for m in models:
+        m.build_vocab(counts=counts)
+    shards = []
+    for r in range(G):
+        b, e = sgns.shard_bounds(n, G, r)
+        idx = (torch.arange(rounds, device=corpus.walks.device)[:, None] * n +
+               torch.arange(b, e, device=corpus.walks.device)[None, :]).reshape(-1)
+        shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
+    n_global = corpus.walks.shape[0]
+    bases = [models[0].syn0.clone(), models[0].syn1neg.clone()]
+    pv = counts.double() / counts.sum()
+    pn = counts.double() ** 0.75
+    pn = pn / pn.sum()
+    T_full = n_global * 80.0 / syncs
+
+    def weight(ti, T):
+        U = 10.5 * T * (pv if ti == 0 else (pv + 5 * pn))
+        lam = torch.clamp(B / ((G - 1) * U / G).clamp_min(1e-30), max=1.0).float()
+        return lam, lam + (1 - lam) / G
+    hot = [weight(ti, T_full)[0] < 1.0 for ti in range(2)]
+    w_sub = [weight(ti, T_full / K)[1] for ti in range(2)]
+    print("   tier: hot rows syn0 %d syn1neg %d of %d" % (int(hot[0].sum()), int(hot[1].sum()), n_nodes), flush=True)
+    for c in range(syncs * K):
+        for r, m in enumerate(models):
+            w, l, off = shards[r]
+            b, e = sgns.shard_bounds(w.shape[0], syncs * K, c)
+            if e > b:
+                m.train_pass(w[b:e], l[b:e], sentences_base=b * G, sentences_step=G, sentences_total=n_global,
+                             walk_id_base=off + b)
+        full = (c + 1) % K == 0
+        for ti, name in enumerate(("syn0", "syn1neg")):
+            rows = torch.nonzero(hot[ti] if not full else torch.ones_like(hot[ti])).flatten()
+            if rows.numel() == 0:
+                continue
+            stack = torch.stack([getattr(m, name)[rows] for m in models])
+            base = bases[ti][rows]
+            wr = torch.where(hot[ti][rows], w_sub[ti][rows], torch.ones_like(w_sub[ti][rows]))
+            new = base + (stack - base[None]).sum(0) * wr[:, None]
+            for m in models:
+                getattr(m, name)[rows] = new
+            bases[ti][rows] = new
+    return models[0]
+
+
 def _hub_partition(n=20000, k=100, m_in=200000, m_out=40000, seed=0):
     """Degree-corrected planted partition: communities + Pareto node activity (hubs)."""
     rs = np.random.RandomState(seed)
@@ -150,7 +201,10 @@ def main():
             for syncs in sync_list:
                 if syncs <= 0:
                     syncs = max(1, auto[G] // (-syncs if syncs < 0 else 1))   # 0: auto, -k: auto/k
-                m = simulate(G, corpus, g.n_nodes, rounds, merge, syncs)
+                if merge.startswith("tier"):
+                    m = simulate_tier(G, corpus, g.n_nodes, rounds, syncs, int(merge[4:] or 8))
+                else:
+                    m = simulate(G, corpus, g.n_nodes, rounds, merge, syncs)
                 auc, ap = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
                 print("G=%d merge=%-10s syncs=%3d: AUC %.5f AP %.5f" % (G, merge, syncs, auc, ap), flush=True)
 
