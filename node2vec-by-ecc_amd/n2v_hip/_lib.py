@@ -34,6 +34,8 @@ SIGNATURES = {
     "n2v_walk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr,
                            _u64, _ptr, _ptr, _ptr]),
     "n2v_mt19937_jump_host": (C.c_int, [_ptr, _i64, _i32, _ptr]),
+    "n2v_mt19937_jump_polys_host": (C.c_int, [_i64, _i32, _ptr]),
+    "n2v_mt19937_jump_device": (C.c_int, [_ptr, _i32, _ptr, _i32, _ptr]),
     "n2v_mt19937_fill": (C.c_int, [_ptr, _i32, _i32, _i64, _i64, _ptr, _ptr, _ptr]),
     "n2v_build_fat_slots": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "n2v_walk_fat": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr, _u64,

@@ -326,6 +326,20 @@ def test_device_mt19937_equals_numpy_stream(n2v):
         st_dev = np.random.get_state()
         assert torch.equal(got, got1)
         assert st_dev[2] == st_want[2] and np.array_equal(st_dev[1], st_want[1]), (seed, pre_words, n)
+    # start states: the device's doubling scheme equals the host's sequential jumps, for stream counts on
+    # both sides of a power of two and for a stride that is not a whole block
+    key = np.random.RandomState(77).get_state()[1]
+    for stride, ns in ((624 * 211, 37), (624 * 5, 64), (1001, 65), (624, 2), (624 * 3000, 1024)):
+        host = mt19937.jump_states(key, stride, min(ns, 80))
+        dev = mt19937.jump_states_device(key, stride, ns, "cuda:0").cpu().numpy().view(np.uint32)
+        assert np.array_equal(dev[: host.shape[0]], host), (stride, ns)
+    np.random.seed(21)
+    want = np.random.random_sample(3_000_001)
+    st_want = np.random.get_state()
+    np.random.seed(21)
+    got = mt19937.global_uniforms_device(3_000_001, "cuda:0", n_streams=733)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(np.random.get_state()[1], st_want[1]) and np.random.get_state()[2] == st_want[2]
     # host-side generation stays available and identical
     z = load_case("karate_p025_q4")
     g = n2v.Graph(_nx_graph(z), False, 0.25, 4.0)

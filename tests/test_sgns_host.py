@@ -120,6 +120,19 @@ for mode in ("avg", "delta", "hot"):
     assert torch.allclose(t, want), (mode, t, want)
     if mode != "avg":
         assert torch.equal(bases[0], t)
+# hot tier: only the listed rows are exchanged and merged (weights per listed row), the others keep their drift
+class P: pass
+plan = P(); plan.rows = [torch.tensor([2]), torch.tensor([], dtype=torch.long)]; plan.w_rows = [torch.tensor([0.5]), torch.tensor([])]
+base0 = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+t0, t1 = base0.clone(), base0.clone()
+bases = [base0.clone(), base0.clone()]
+t0[rank] += 1.0 + rank; t0[2] += 10.0 * (rank + 1); t1[1] += 7.0
+sgns.merge_hot_rows([t0, t1], bases, comm, plan)
+want = base0.clone(); want[rank] += 1.0 + rank; want[2] += 15.0
+assert torch.allclose(t0, want), (t0, want)
+assert torch.equal(bases[0][2], t0[2]) and torch.equal(bases[0][:2], base0[:2])
+w1 = base0.clone(); w1[1] += 7.0
+assert torch.equal(t1, w1) and torch.equal(bases[1], base0)
 b, e = sgns.shard_bounds(101, 2, rank)
 tot = torch.tensor([e - b]); dist.all_reduce(tot); assert int(tot) == 101
 dist.destroy_process_group()
@@ -154,3 +167,22 @@ def test_build_neg_samples_and_isolated_nodes():
     t2 = linkpred._with_isolated_nodes(train, full)
     assert t2.n_nodes == 5 and t2.degrees.tolist() == [1, 2, 1, 0, 0]
     assert t2.labels[t2.col].tolist() == [2, 0, 4, 2] and np.array_equal(t2.start_order, full.start_order)
+
+
+def test_tier_plan_selects_hub_rows_and_degenerates_without_them():
+    import torch
+    from n2v_hip import sgns
+    counts = np.full(1000, 100, dtype=np.int64)
+    counts[:5] = 200000                                   # five hubs
+    T = counts.sum() / 20.0                               # tokens per full interval
+    plan = sgns.TierPlan(counts, T, 8, 10, 5, torch.device("cpu"))
+    assert plan.every == sgns.HOT_EVERY
+    assert plan.rows[0].tolist() == [0, 1, 2, 3, 4] and set(range(5)) <= set(plan.rows[1].tolist())
+    w_sub = sgns.merge_weights(counts, T / plan.every, 8, 10, 5, torch.device("cpu"))
+    w_full = sgns.merge_weights(counts, T, 8, 10, 5, torch.device("cpu"))
+    assert torch.equal(plan.w_rows[0], w_sub[0][:5])
+    cold = torch.ones(1000, dtype=torch.bool); cold[plan.rows[0]] = False
+    assert torch.equal(plan.w_full[0][cold], w_full[0][cold]) and torch.equal(plan.w_full[0][:5], w_sub[0][:5])
+    assert (plan.w_rows[0] >= 1 / 8 - 1e-6).all() and (plan.w_full[0] <= 1).all()
+    flat = sgns.TierPlan(np.full(1000, 100), 1000.0, 8, 10, 5, torch.device("cpu"))   # nobody is hot
+    assert flat.every == 1 and all(r.numel() == 0 for r in flat.rows)

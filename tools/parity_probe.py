@@ -23,7 +23,7 @@ def main():
     torch.cuda.synchronize()
     # generator alone
     for n in (10**6, 10**8):
-        for streams in (1, 32, 128):
+        for streams in (1, 128, 1024, 1024, 4096, 4096, 8192, 8192):
             np.random.seed(1)
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -33,6 +33,19 @@ def main():
             print("mt19937 device: n=%.0e streams=%3d  %.4fs  %.3e doubles/s" % (n, streams, dt, n / dt), flush=True)
             del u
     res = {}
+    g.host_rng = False
+    np.random.seed(5)
+    g.simulate_walks(1, 80)   # warm-up: jump polynomials of the batch strides, allocator
+    for r10 in (10,):
+        np.random.seed(123)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        c = g.simulate_walks(r10, 80)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        print("%s rng=numpy (device uniforms, warm), %d rounds: %.3fs  %.3e steps/s end to end" % (
+            name, r10, dt, int((c.lens.long() - 1).sum().item()) / dt), flush=True)
+        del c
     for host in (False, True):
         g.host_rng = host
         np.random.seed(123)

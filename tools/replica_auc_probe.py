@@ -65,7 +65,7 @@ def simulate(G, corpus, n_nodes, rounds, merge, syncs, mode="atomic"):
     return models[0]
 
 
-def simulate_tier(G, corpus, n_nodes, rounds, syncs, K, B=256.0, mode="atomic"):
+def simulate_tier(G, corpus, n_nodes, rounds, syncs, K, B=256.0, mode="atomic", thr=1.0):
     """Two-tier merge: rows whose expected updates per full interval exceed the budget B (hubs, frequent
     negatives) are merged K times per full interval (small message), all rows once per full interval.
     Weights as merge 'hot', computed for the interval a row actually waited."""
@@ -91,7 +91,7 @@ def simulate_tier(G, corpus, n_nodes, rounds, syncs, K, B=256.0, mode="atomic"):
         U = 10.5 * T * (pv if ti == 0 else (pv + 5 * pn))
         lam = torch.clamp(B / ((G - 1) * U / G).clamp_min(1e-30), max=1.0).float()
         return lam, lam + (1 - lam) / G
-    hot = [weight(ti, T_full)[0] < 1.0 for ti in range(2)]
+    hot = [weight(ti, T_full)[0] < 1.0 / thr for ti in range(2)]   # expected updates above thr x budget
     w_sub = [weight(ti, T_full / K)[1] for ti in range(2)]
     print("   tier: hot rows syn0 %d syn1neg %d of %d" % (int(hot[0].sum()), int(hot[1].sum()), n_nodes), flush=True)
     for c in range(syncs * K):
@@ -108,7 +108,7 @@ def simulate_tier(G, corpus, n_nodes, rounds, syncs, K, B=256.0, mode="atomic"):
                 continue
             stack = torch.stack([getattr(m, name)[rows] for m in models])
             base = bases[ti][rows]
-            wr = torch.where(hot[ti][rows], w_sub[ti][rows], torch.ones_like(w_sub[ti][rows]))
+            wr = torch.where(hot[ti][rows], w_sub[ti][rows], weight(ti, T_full)[1][rows])
             new = base + (stack - base[None]).sum(0) * wr[:, None]
             for m in models:
                 getattr(m, name)[rows] = new
@@ -196,13 +196,14 @@ def main():
     auto = {G: sgns.auto_syncs(corpus.walks.shape[0] * 80, g.n_nodes, G) for G in (2, 8)}
     print("auto syncs:", auto, flush=True)
     sync_list = [int(x) for x in os.environ.get("SYNCS", "4,16,64").split(",")]
-    for G in (2, 8):
+    for G in [int(x) for x in os.environ.get("GS", "2,8").split(",")]:
         for merge in os.environ.get("MERGES", "sparse_avg,avg,delta").split(","):
             for syncs in sync_list:
                 if syncs <= 0:
                     syncs = max(1, auto[G] // (-syncs if syncs < 0 else 1))   # 0: auto, -k: auto/k
                 if merge.startswith("tier"):
-                    m = simulate_tier(G, corpus, g.n_nodes, rounds, syncs, int(merge[4:] or 8))
+                    k, _, thr = merge[4:].partition("x")     # tier8x2: 8 sub-merges, rows above 2x the budget
+                    m = simulate_tier(G, corpus, g.n_nodes, rounds, syncs, int(k or 8), thr=float(thr or 1))
                 else:
                     m = simulate(G, corpus, g.n_nodes, rounds, merge, syncs)
                 auc, ap = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
