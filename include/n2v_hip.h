@@ -155,12 +155,12 @@ int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat, const n2v
 int n2v_mt19937_jump_host(const uint32_t* key_host, int64_t stride_words, int32_t n_streams,
                           uint32_t* states_host);
 /* The same start states computed on the device, by doubling: with the host-made polynomials
- * x^(stride_words * 2^r) mod x*phi(x), r < n_rounds (n2v_mt19937_jump_polys_host: uint64[n_rounds][312] on the
- * host, copied to the device by the caller), round r derives streams [2^r, 2^(r+1)) from streams [0, 2^r).
+ * x^(stride_words * 2^r) mod x*phi(x), r < n_rounds (n2v_mt19937_jump_polys_host: uint32[n_rounds][19968] on the
+ * host — per polynomial the number of set bits, then their positions — copied to the device by the caller), round r derives streams [2^r, 2^(r+1)) from streams [0, 2^r).
  * states: DEVICE uint32[n_streams][624], states[0] = the caller's key on entry.  A thousand streams cost about a
  * millisecond instead of the host's half a millisecond each, which lets n2v_mt19937_fill use the whole chip. */
-int n2v_mt19937_jump_polys_host(int64_t stride_words, int32_t n_rounds, uint64_t* polys_host);
-int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, const uint64_t* polys, int32_t n_rounds,
+int n2v_mt19937_jump_polys_host(int64_t stride_words, int32_t n_rounds, uint32_t* polys_host);
+int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, const uint32_t* polys, int32_t n_rounds,
                             void* stream);
 int n2v_mt19937_fill(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
                      int64_t n_doubles, double* out, uint32_t* final_state, void* stream);

@@ -278,22 +278,23 @@ mt_fill_kernel(const uint32_t* __restrict__ states, int pos0, int64_t words_per_
 // new stream: the sequence x that continues the source window (deg + 624 words, 82 KB) is generated into LDS —
 // 192 words per round, a word depends only on words at least 227 places back — and (g(A) w)[j] = XOR over the
 // set bits i of g of x[i + j] is accumulated with every thread holding three of the 624 window words.
-constexpr int kJumpThreads = 256;
-constexpr int kSeqWords = kModDeg + kN;  // 20592
+constexpr int kJumpThreads = 640;  // ten wavefronts: one window word per thread, latency hidden by the other waves
+constexpr int kSeqWords = kModDeg + kN;   // 20592
+constexpr int kPosRow = 19968;            // uint32 per polynomial: [0] = number of set bits, then their positions
 
 __global__ void __launch_bounds__(kJumpThreads)
-mt_jump_kernel(uint32_t* __restrict__ states, const uint64_t* __restrict__ poly, int src_count, int n_new) {
-    extern __shared__ uint32_t x[];  // [kSeqWords] then the polynomial: kPW 64-bit words
-    uint64_t* g = reinterpret_cast<uint64_t*>(x + kSeqWords);
+mt_jump_kernel(uint32_t* __restrict__ states, const uint32_t* __restrict__ pos, int src_count, int n_new) {
+    extern __shared__ uint32_t x[];  // [kSeqWords] words of the sequence, then the set-bit positions as uint16
+    uint16_t* P = reinterpret_cast<uint16_t*>(x + kSeqWords);
     const int t = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= n_new) return;
     const uint32_t* in = states + (size_t)b * kN;
     for (int i = t; i < kN; i += kJumpThreads) x[i] = in[i];
-    for (int i = t; i < kPW; i += kJumpThreads) g[i] = poly[i];
+    const int n_set = (int)pos[0];
+    const int deg = n_set ? (int)pos[n_set] : 0;  // positions ascend: the last one is the degree
+    for (int i = t; i < n_set; i += kJumpThreads) P[i] = (uint16_t)pos[1 + i];
     __syncthreads();
-    int deg = kModDeg - 1;  // highest set bit of g (same in all threads)
-    while (deg > 0 && !((g[deg >> 6] >> (deg & 63)) & 1ULL)) --deg;
     for (int n0 = kN; n0 < deg + kN; n0 += 192) {
         const int n = n0 + t;
         if (t < 192 && n < deg + kN) {
@@ -302,22 +303,20 @@ mt_jump_kernel(uint32_t* __restrict__ states, const uint64_t* __restrict__ poly,
         }
         __syncthreads();
     }
-    uint32_t a0 = 0, a1 = 0, a2 = 0;
-    const bool has2 = t + 2 * kJumpThreads < kN;
-    for (int wi = 0; wi <= (deg >> 6); ++wi) {
-        uint64_t w = g[wi];
-        while (w) {
-            const int i = (wi << 6) + __builtin_ctzll(w);
-            w &= w - 1;
-            a0 ^= x[i + t];
-            a1 ^= x[i + t + kJumpThreads];
-            if (has2) a2 ^= x[i + t + 2 * kJumpThreads];
-        }
+    // per set bit a thread issues one LDS read and one XOR; the positions sit in LDS as uint16 (staged by the
+    // first loop above) and are consumed eight at a time so that the reads of one group overlap
+    uint32_t a0 = 0;
+    const uint32_t* xt = x + (t < kN ? t : 0);
+    int k = 0;
+    for (; k + 8 <= n_set; k += 8) {
+        uint32_t i[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) i[j] = P[k + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a0 ^= xt[i[j]];
     }
-    uint32_t* out = states + (size_t)(src_count + b) * kN;
-    out[t] = a0;
-    out[t + kJumpThreads] = a1;
-    if (has2) out[t + 2 * kJumpThreads] = a2;
+    for (; k < n_set; ++k) a0 ^= xt[P[k]];
+    if (t < kN) states[(size_t)(src_count + b) * kN + t] = a0;
 }
 
 }  // namespace
@@ -355,16 +354,21 @@ extern "C" int n2v_mt19937_jump_host(const uint32_t* key_host, int64_t stride_wo
     return N2V_OK;
 }
 
-// Coefficient bits of x^(stride_words * 2^r) mod x*phi(x), r = 0 .. n_rounds-1 (uint64[n_rounds][312], host):
-// the jump polynomials of the doubling scheme used by n2v_mt19937_jump_device.
-extern "C" int n2v_mt19937_jump_polys_host(int64_t stride_words, int32_t n_rounds, uint64_t* polys_host) {
+// Set-bit positions of x^(stride_words * 2^r) mod x*phi(x), r = 0 .. n_rounds-1, as uint32[n_rounds][19968] on the
+// host: word 0 = number of set bits, then the positions in ascending order — the jump polynomials of the
+// doubling scheme used by n2v_mt19937_jump_device.
+extern "C" int n2v_mt19937_jump_polys_host(int64_t stride_words, int32_t n_rounds, uint32_t* polys_host) {
     if (!polys_host || stride_words < 1 || n_rounds < 1 || n_rounds > 32)
         return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_polys_host: bad argument");
     build_modulus();
     if (!g_mt.ready) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_polys_host: minimal polynomial not found");
     Poly g = powmod_x((uint64_t)stride_words), t;
     for (int r = 0; r < n_rounds; ++r) {
-        std::memcpy(polys_host + (size_t)r * kPW, g.data(), sizeof(uint64_t) * kPW);
+        uint32_t* row = polys_host + (size_t)r * kPosRow;
+        uint32_t n = 0;
+        for (int i = 0; i < kModDeg; ++i)
+            if (pbit(g, i)) row[++n] = (uint32_t)i;
+        row[0] = n;
         if (r + 1 < n_rounds) {
             mulmod(g, g, t);
             g.swap(t);
@@ -377,7 +381,7 @@ extern "C" int n2v_mt19937_jump_polys_host(int64_t stride_words, int32_t n_round
 // by k * stride_words outputs, for every k < n_streams.  polys: DEVICE copy of the n_rounds >= ceil(log2
 // (n_streams)) polynomials above.  Round r computes streams [2^r, 2^(r+1)) from streams [0, 2^r): one launch
 // per round, every new stream in its own workgroup.
-extern "C" int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, const uint64_t* polys, int32_t n_rounds,
+extern "C" int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, const uint32_t* polys, int32_t n_rounds,
                                        void* stream) {
     if (!states || n_streams < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_device: bad argument");
     int need = 0;
@@ -386,7 +390,7 @@ extern "C" int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, cons
     if (!polys || n_rounds < need)
         return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_device: %d streams need %d polynomials, got %d", (int)n_streams,
                          need, (int)n_rounds);
-    const size_t lds = sizeof(uint32_t) * kSeqWords + sizeof(uint64_t) * kPW;
+    const size_t lds = sizeof(uint32_t) * kSeqWords + sizeof(uint16_t) * kPosRow;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_jump_kernel),
@@ -398,7 +402,7 @@ extern "C" int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, cons
         const int src = 1 << r;
         const int n_new = n_streams - src < src ? n_streams - src : src;
         hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)n_new), dim3(kJumpThreads), lds, (hipStream_t)stream, states,
-                           polys + (size_t)r * kPW, src, n_new);
+                           polys + (size_t)r * kPosRow, src, n_new);
     }
     return n2v::check_launch("n2v_mt19937_jump_device");
 }
