@@ -153,6 +153,45 @@ class WalkEngine:
         s = self.edge_slots[off[0]:off[1]]
         return (self.slots_J(s).cpu().numpy().astype(np.int64), self.slots_q(s).cpu().numpy())
 
+    def build_one_node_table(self, dense):
+        """get_alias_nodes_cur (src/node2vec.py:13-21, popwalk "none"): the table of one node, built on demand."""
+        b, e = int(self.csr.row_ptr[dense]), int(self.csr.row_ptr[dense + 1])
+        d = self.device
+        with torch.cuda.device(d):
+            slots = torch.zeros((max(e - b, 1), 2), dtype=torch.int64, device=d)
+            status = torch.zeros(1, dtype=torch.int32, device=d)
+            rp = torch.tensor([0, e - b], dtype=torch.int64, device=d)
+            w = None if self.w is None else self.w[b:e].contiguous()
+            _lib.check(self.lib.n2v_build_node_tables(1, _lib.ptr(rp), self.col[b:].data_ptr() if e > b else None,
+                                                      _lib.ptr(w), _lib.ptr(slots), _lib.ptr(status), self._stream()))
+            if int(status.item()) & _lib.N2V_STATUS_ZERO_NORM:
+                raise ZeroDivisionError("float division by zero")
+        s = slots[: e - b]
+        return (self.slots_J(s).cpu().numpy().astype(np.int64), self.slots_q(s).cpu().numpy())
+
+    def build_one_edge_table(self, e):
+        """get_alias_edge (src/node2vec.py:133-152) for one CSR entry e = (src -> dst), built on demand by the
+        same kernel that fills the stored tables (one-table launch: the kernel reads src_of[e] and edge_off[e]
+        only, so one-element arrays are passed with their base shifted by -e)."""
+        dst = int(self.csr.col[e])
+        K = int(self.csr.row_ptr[dst + 1] - self.csr.row_ptr[dst])
+        src = int(np.searchsorted(self.csr.row_ptr, e, side="right") - 1)
+        d = self.device
+        with torch.cuda.device(d):
+            slots = torch.zeros((max(K, 1), 2), dtype=torch.int64, device=d)
+            status = torch.zeros(1, dtype=torch.int32, device=d)
+            off = torch.zeros(1, dtype=torch.int64, device=d)
+            src_of = torch.tensor([src], dtype=torch.int32, device=d)
+            order = torch.tensor([e], dtype=torch.int64, device=d).to(torch.int32)
+            _lib.check(self.lib.n2v_build_edge_tables(
+                self.csr.n_nodes, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), src_of.data_ptr() - 4 * e,
+                self.p, self.q, 0 if self.csr.directed else 1, off.data_ptr() - 8 * e, _lib.ptr(order), 0, 1,
+                _lib.ptr(slots), _lib.ptr(status), self._stream()))
+            if int(status.item()) & _lib.N2V_STATUS_ZERO_NORM:
+                raise ZeroDivisionError("float division by zero")
+        s = slots[:K]
+        return (self.slots_J(s).cpu().numpy().astype(np.int64), self.slots_q(s).cpu().numpy())
+
     # ------------------------------------------------------------------ walks
     def walk(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
              pos_begin=0, pos_count=None, round_begin=0, out=None, layout=None):

@@ -234,6 +234,35 @@ class Graph():
         self.alias_edges = _AliasEdges(self)
         return
 
+    def get_alias_edge(self, src, dst):
+        """src/node2vec.py:133-152: the (J, q) alias table of the step that arrives at `dst` from `src`, built by
+        the table kernel for this one pair (no stored tables needed)."""
+        self._check_popwalk()
+        try:
+            du, dv = (int(x) for x in self._csr.dense_of([src, dst]))
+        except (KeyError, TypeError, ValueError):
+            raise KeyError((src, dst))
+        if self.p == 0 or self.q == 0:
+            raise ZeroDivisionError("float division by zero")
+        eng = self._graph_engine()
+        e = eng.edge_index(du, dv)
+        if e < 0:
+            raise KeyError((src, dst))
+        return eng.build_one_edge_table(e)
+
+    def get_alias_edges_cur(self, src, dst):
+        """src/node2vec.py:27-32 (popwalk "none")."""
+        return self.get_alias_edge(src, dst)
+
+    def get_alias_nodes_cur(self, cur):
+        """src/node2vec.py:13-21 (popwalk "none"): the node table of `cur`, built on demand."""
+        self._check_popwalk()
+        try:
+            dc = int(self._csr.dense_of([cur])[0])
+        except (KeyError, TypeError, ValueError):
+            raise KeyError(cur)
+        return self._graph_engine().build_one_node_table(dc)
+
     def _starts(self, nodes):
         c = self._csr
         if not nodes:
@@ -265,6 +294,12 @@ class Graph():
         otf = self._otf_engine()
         walks, lens = self._simulate(num_walks, walk_length, self._starts(nodes), otf=otf)
         return WalkCorpus(walks, lens, self._csr.labels)
+
+    def _graph_engine(self):
+        """The engine with the graph on the device (tables or not)."""
+        if self._engine is None:
+            self._engine = WalkEngine(self._csr, self.p, self.q, device=self.device)
+        return self._engine
 
     def _otf_engine(self):
         """True if the on-the-fly kernel has to (or is asked to) run; makes sure an engine

@@ -96,6 +96,20 @@ def test_tables_match_reference(n2v, name):
     assert (10**15, 1) not in g.alias_edges
     with pytest.raises(KeyError):
         g.alias_edges[(nodes[0], 10**15)]
+    # get_alias_edge / get_alias_edges_cur / get_alias_nodes_cur (src/node2vec.py:13-32,133-152): one table built
+    # on demand, on a graph object that never ran preprocess_transition_probs
+    g2 = n2v.Graph(_nx_graph(z), bool(z["directed"]), float(z["p"]), float(z["q"]))
+    for i in list(range(0, len(z["ae_keys"]), max(1, len(z["ae_keys"]) // 25)))[:40]:
+        u, v = z["ae_keys"][i].tolist()
+        for fn in (g2.get_alias_edge, g2.get_alias_edges_cur):
+            J, q = fn(u, v)
+            assert np.array_equal(J, z["ae_J"][ep[i]:ep[i + 1]]), (u, v)
+            assert np.array_equal(_bits(q), _bits(z["ae_q"][ep[i]:ep[i + 1]])), (u, v)
+    for i, v in list(enumerate(nodes))[:: max(1, len(nodes) // 20)]:
+        J, q = g2.get_alias_nodes_cur(v)
+        assert np.array_equal(J, z["an_J"][ap[i]:ap[i + 1]]) and np.array_equal(_bits(q), _bits(z["an_q"][ap[i]:ap[i + 1]]))
+    with pytest.raises(KeyError):
+        g2.get_alias_edge(nodes[0], 10**15)
 
 
 @pytest.mark.parametrize("name", GRAPH_CASES)
