@@ -289,3 +289,65 @@ def test_hits_raises_like_networkx_when_it_does_not_converge():
     e = bine.BineEngine(bine.BipartiteGraph(users, items, w), device="cuda:0")
     with pytest.raises(bine.BineConvergenceError):
         e.calculate_centrality(max_iter=5, tol=1e-30)
+
+
+def test_config5_size_properties():
+    """BASELINE config 5's shape at full size (500k users, 500k items, 2e7 ratings, d = 256) through properties
+    that do not need the oracle: walk counts follow the authority rule, every walk starts at its vertex, stays on
+    its side and moves between vertices that share a neighbour, lengths are geometric, pools avoid the vertex
+    itself, the occurrence index is a permutation grouped by vertex, and the two parallel training variants agree."""
+    import torch
+    from scipy import stats
+    from n2v_hip import bine, synth
+    u, i, r = synth.bipartite_powerlaw_ratings(500_000, 500_000, 20_000_000)
+    g = bine.BipartiteGraph(u, i, r)
+    e = bine.BineEngine(g, device="cuda:0", seed=42)
+    e.calculate_centrality()
+    e.generate_walks(0.15, 32, 1)
+    auth, counts = e.auth_scaled, e.counts.long()
+    want = torch.clamp(torch.ceil(32 * auth), min=1).long()
+    assert (auth.min() == 0) and (auth[: g.n_u].max() == 1) and (auth[g.n_u:].max() == 1)
+    assert torch.equal(counts, want)
+    off, tok, node = e.walk_off, e.tokens.long(), e.walk_node.long()
+    assert torch.equal(tok[off[:-1]], node)
+    lens = (off[1:] - off[:-1])
+    side_tok = tok >= g.n_u
+    assert torch.equal(side_tok, side_tok[off[:-1]][e.tok_walk.long()])            # a walk never changes side
+    inner = torch.ones_like(tok, dtype=torch.bool)
+    inner[off[1:-1]] = False
+    inner[0] = False                                                                # positions that have a predecessor
+    assert (tok[1:][inner[1:]] != tok[:-1][inner[1:]]).all()                        # never stays put
+    # geometric lengths: P(len = k) = 0.15 * 0.85^(k-1) over the walks whose start is not a dead end
+    deg2 = (e.cum2[e.row_ptr[1:]] - e.cum2[e.row_ptr[:-1]]) - (e.row_ptr[1:] - e.row_ptr[:-1])
+    live = (deg2[node] > 0)
+    ll = lens[live].cpu().numpy()
+    assert (lens[~live] == 1).all()
+    ks = np.arange(1, 40)
+    obs = np.array([(ll == k).sum() for k in ks], dtype=np.float64)
+    exp = len(ll) * 0.15 * 0.85 ** (ks - 1)
+    assert stats.chi2.sf(((obs - exp) ** 2 / exp).sum(), len(ks) - 1) > 1e-4
+    # sampled steps connect vertices with a common neighbour
+    rs = np.random.RandomState(0)
+    pos = np.nonzero(inner.cpu().numpy())[0]
+    tk = tok.cpu().numpy()
+    for p in rs.choice(pos, 3000, replace=False):
+        a, b = int(tk[p - 1]), int(tk[p])
+        ra, rb = g.col[g.row_ptr[a]:g.row_ptr[a + 1]], g.col[g.row_ptr[b]:g.row_ptr[b + 1]]
+        assert np.intersect1d(ra, rb, assume_unique=True).size > 0, (a, b)
+    e.build_negative_pools(200)
+    pool = e.pool.long()
+    ids = torch.arange(g.n, device=pool.device)[:, None]
+    assert (pool != ids).all() and ((pool >= g.n_u) == (ids >= g.n_u)).all()
+    e.build_occurrences()
+    assert torch.equal(torch.sort(e.occ_pos).values, torch.arange(tok.numel(), device=tok.device))
+    grouped = tok[e.occ_pos]
+    assert (grouped[1:] >= grouped[:-1]).all()
+    assert torch.equal(e.occ_ptr[1:] - e.occ_ptr[:-1], torch.bincount(tok, minlength=g.n))
+    e.init_embeddings(256)
+    e0, c0 = e.emb.clone(), e.ctx.clone()
+    a = e.train(max_iter=2, mode="atomic")
+    e.emb.copy_(e0)
+    e.ctx.copy_(c0)
+    b = e.train(max_iter=2, mode="store")
+    assert e.mode_used == "store" and np.allclose(a, b, rtol=1e-3)
+    assert torch.isfinite(e.emb).all() and torch.isfinite(e.ctx).all() and (e.emb[:, 256:].numel() == 0)
