@@ -188,6 +188,7 @@ def merge_replicas(tables, bases, comm, mode="hot", weights=None):
 
 HOT_BUDGET = 256.0  # updates per replica and interval above which a row is merged towards the mean
 HOT_EVERY = 8       # merges of the hot tier per full merge
+MIN_WALKS_PER_LAUNCH = 8192  # one wavefront trains one walk at a time: shorter launches leave the chip idle
 HOT_TIER_FACTOR = 2.0  # a row is in the hot tier when its expected updates per full interval exceed this many budgets
 
 
@@ -275,10 +276,19 @@ def chunk_plan(n_local, n_chunks):
     return [shard_bounds(n_local, n_chunks, c) for c in range(n_chunks)]
 
 
+def hot_every_for(n_local, n_chunks, hot_every="auto"):
+    """Hot-tier merges per full interval: HOT_EVERY, reduced so that a launch still covers MIN_WALKS_PER_LAUNCH walks
+    (at C3 on 8 GPUs the full interval itself is already that short, and the tier is off)."""
+    if hot_every != "auto":
+        return max(1, int(hot_every))
+    return max(1, min(HOT_EVERY, n_local // (max(n_chunks, 1) * MIN_WALKS_PER_LAUNCH)))
+
+
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
-          merge="hot"):
+          merge="hot", hot_every="auto"):
     """Train `epochs` passes over this rank's walks.  With a communicator the replicas are
-    merged `syncs_per_epoch` times per pass ("auto": auto_syncs), the last one at its end."""
+    merged `syncs_per_epoch` times per pass ("auto": auto_syncs), the last one at its end; the hot tier
+    (TierPlan) `hot_every` times per full interval."""
     n_local = int(walks.shape[0])
     if n_walks_global is None:
         n_walks_global = n_local
@@ -293,7 +303,7 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
     weights, tier = None, None
     if world > 1 and merge == "hot":
         tier = TierPlan(model.counts, n_walks_global * int(walks.shape[1]) / max(1, min(n_chunks, max(n_local, 1))), world,
-                        model.window, model.negative, model.device)
+                        model.window, model.negative, model.device, every=hot_every_for(n_local, n_chunks, hot_every))
         weights = tier.w_full
     every = tier.every if tier is not None else 1
     plan = chunk_plan(n_local, n_chunks * every)
@@ -327,7 +337,8 @@ class _SimulatedComm:
         self._i += 1
 
 
-def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="hot", epochs=1):
+def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="hot", epochs=1,
+                             hot_every="auto"):
     """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens,
     shard_offset)` what rank r would hold.  Runs the same schedule and the same merge_replicas
     arithmetic as `train`, interval by interval, so the multi-GPU scheme can be scored for AUC
@@ -341,7 +352,7 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
     if merge == "hot":
         n0 = int(shards[0][0].shape[0])
         tier = TierPlan(models[0].counts, n_walks_global * L / max(1, min(n_chunks, max(n0, 1))), G, models[0].window,
-                        models[0].negative, models[0].device)
+                        models[0].negative, models[0].device, every=hot_every_for(n0, n_chunks, hot_every))
         weights = tier.w_full
     every = tier.every if tier is not None else 1
     plans = [chunk_plan(int(w.shape[0]), n_chunks * every) for w, _, _ in shards]

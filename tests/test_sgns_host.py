@@ -186,3 +186,12 @@ def test_tier_plan_selects_hub_rows_and_degenerates_without_them():
     assert (plan.w_rows[0] >= 1 / 8 - 1e-6).all() and (plan.w_full[0] <= 1).all()
     flat = sgns.TierPlan(np.full(1000, 100), 1000.0, 8, 10, 5, torch.device("cpu"))   # nobody is hot
     assert flat.every == 1 and all(r.numel() == 0 for r in flat.rows)
+
+
+def test_hot_tier_frequency_respects_launch_size():
+    from n2v_hip import sgns
+    # C3 shapes: 10M walks per rank; 2 ranks -> 67 full merges, 8 ranks -> 1867
+    assert sgns.hot_every_for(10_000_000, 67) == sgns.HOT_EVERY
+    assert sgns.hot_every_for(10_000_000, 400) == 3
+    assert sgns.hot_every_for(10_000_000, 1867) == 1          # the full interval is already below one launch
+    assert sgns.hot_every_for(25_000, 234) == 1 and sgns.hot_every_for(25_000, 234, 8) == 8
