@@ -69,7 +69,41 @@ def cpu_baselines(cg, p, q, walks_sample, lens_sample, counts, dim, budget_s=12.
         "sample": "first %d start vertices x 1 round x L=80 of the same graph; pure-Python restatement of "
                   "src/node2vec.py (on-the-fly tables as src/settings.py:18, per-step sorted neighbours, two "
                   "MT19937 draws per step); %.1f s" % (done, dt)}
-    extra = {"host_cpus": os.cpu_count()}
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    model = "?"
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    extra = {"host_cpus": os.cpu_count(), "affinity_cpus": affinity, "cpu_model": model}
+    # the same restatement fanned out over processes by contiguous blocks of start nodes, as
+    # src/main_link.py:259-292 does (spawned workers: this process owns a GPU context and must not fork)
+    if cg.w is None:
+        import subprocess
+        import tempfile
+        procs = max(1, min(16, affinity))
+        with tempfile.TemporaryDirectory() as td:
+            base = os.path.join(td, "g")
+            for k, a in (("labels", cg.labels), ("row_ptr", cg.row_ptr), ("col", cg.col), ("start_order", cg.start_order)):
+                np.save("%s_%s.npy" % (base, k), np.asarray(a))
+            per = 400
+            t0 = time.perf_counter()
+            ps = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_workers", base, "1" if cg.directed else "0", str(p),
+                                    str(q), str(r * per), str((r + 1) * per), "6.0", str(1000 + r)], cwd=ROOT,
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for r in range(procs)]
+            res = []
+            for pr in ps:
+                try:
+                    res.append(json.loads(pr.communicate(timeout=60)[0].strip().splitlines()[-1]))
+                except Exception:
+                    pr.kill()
+            wall = time.perf_counter() - t0
+        if res:
+            busy = max(r[2] for r in res)
+            extra["walk_python_processes"] = {
+                "value": sum(r[0] for r in res) / busy, "unit": "walk-steps/s", "cores": len(res),
+                "sample": "%d processes x up to %d start vertices each x 1 round (slowest worker %.1f s, %.1f s with "
+                          "start-up)" % (len(res), per, busy, wall)}
     # C port of the walk (table rebuilt per step), 1 thread, 20000 starts
     co = c_oracle.CsrOracle(cg.row_ptr, cg.col, cg.w, p, q)
     t0 = time.perf_counter()
@@ -78,6 +112,18 @@ def cpu_baselines(cg, p, q, walks_sample, lens_sample, counts, dim, budget_s=12.
     dt = time.perf_counter() - t0
     extra["walk_c_port_on_the_fly"] = {"value": float((l - 1).sum()) / dt, "unit": "walk-steps/s", "cores": 1,
                                        "sample": "%d start vertices x 1 round" % ns}
+    # the same C port on all cores: threads take contiguous blocks of start vertices (Philox keyed by walk index)
+    from concurrent.futures import ThreadPoolExecutor
+    T = max(1, min(64, affinity))
+    blocks = [cg.start_order[k * ns // T:(k + 1) * ns // T] for k in range(T)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(T) as ex:
+        outs = list(ex.map(lambda kb: co.walk(kb[1], 4, 80, mode="philox", seed=1, walk_index_base=kb[0] * 10**6,
+                                              on_the_fly=True)[1], enumerate(blocks)))
+    dt = time.perf_counter() - t0
+    extra["walk_c_port_on_the_fly_allcores"] = {"value": float(sum((x - 1).sum() for x in outs)) / dt,
+                                                "unit": "walk-steps/s", "cores": T,
+                                                "sample": "%d start vertices x 4 rounds over %d threads" % (ns, T)}
     # SGNS restatement on a sample of the GPU-generated walks
     si, cum = sgns_oracle.vocab_tables(counts, 1e-3) if cg.n_nodes <= 200000 else (None, None)
     if si is None:
