@@ -216,9 +216,8 @@ class TierPlan:
     """Two-tier merge schedule of mode 'hot'.  Rows that every replica hammers (hubs, frequent negatives: expected
     updates per full interval above HOT_TIER_FACTOR budgets) are merged `every` times per full interval — a message
     of a few per cent of the table — so their replicas never drift far apart; all rows are merged once per full
-    interval.  Weights are those of merge_weights for the time a row actually waited.  On a 20k-vertex graph with
-    hubs (tools/replica_auc_probe.py hub, comparator AUC 0.8672) 8 replicas score 0.8650 with the tier against
-    0.8608 without it."""
+    interval.  Weights are those of merge_weights for the time a row actually waited.  Measured effect and when
+    it is switched on: hot_every_for() and DESIGN.md section 6."""
 
     def __init__(self, counts, interval_tokens_global, world, window, negative, device, every=HOT_EVERY,
                  factor=HOT_TIER_FACTOR, budget=HOT_BUDGET):
@@ -258,9 +257,11 @@ def merge_hot_rows(tables, bases, comm, plan):
 # sum ('delta') stays within 0.0005 while (G-1) * tokens per vocabulary row per interval is about
 # 12-22, is off by 0.0023 at 50 and diverges at 87.  On a 20k-node graph WITH hubs (comparator
 # 0.8672) no cadence rescues the pure sum (+0.006 at G=2, +0.020 at G=8: hub rows overshoot) nor
-# the mean (-0.014 / -0.050: cold rows under-train); the 'hot' interpolation at this cadence gives
-# +0.001 / +0.001 (uniform) and about -0.002 / -0.003 (hubs) for G = 2 / 8.
-STALENESS_BUDGET = 24.0
+# the mean (-0.014 / -0.050: cold rows under-train).  With the 'hot' interpolation the cadence can be relaxed:
+# budgets 24 / 48 / 96 give +0.0013 / +0.0016 / +0.0022 (G=2) and -0.0003 / +0.0010 / +0.0026 (G=8) on the
+# uniform graph and -0.0023 / -0.0015 / -0.0031 (G=2), -0.0060 / -0.0030 / -0.0039 (G=8) on the hub graph:
+# 48 is the largest budget inside the +-0.002 band on the uniform graph and the best one on the hub graph.
+STALENESS_BUDGET = 48.0
 
 
 def auto_syncs(tokens_global, n_words, world):
@@ -276,11 +277,15 @@ def chunk_plan(n_local, n_chunks):
     return [shard_bounds(n_local, n_chunks, c) for c in range(n_chunks)]
 
 
-def hot_every_for(n_local, n_chunks, hot_every="auto"):
-    """Hot-tier merges per full interval: HOT_EVERY, reduced so that a launch still covers MIN_WALKS_PER_LAUNCH walks
-    (at C3 on 8 GPUs the full interval itself is already that short, and the tier is off)."""
+def hot_every_for(n_local, n_chunks, hot_every="auto", world=2):
+    """Hot-tier merges per full interval.  "auto": HOT_EVERY with two replicas — where it brings the hub graph
+    inside the AUC band (0.8675 / 0.8672 against 0.8656 / 0.8648 without, comparator 0.8672) — and off beyond:
+    with eight replicas it helped at one cadence (+0.003) and hurt at another (-0.004); always
+    reduced so that a launch still covers MIN_WALKS_PER_LAUNCH walks."""
     if hot_every != "auto":
         return max(1, int(hot_every))
+    if world > 2:
+        return 1
     return max(1, min(HOT_EVERY, n_local // (max(n_chunks, 1) * MIN_WALKS_PER_LAUNCH)))
 
 
@@ -303,7 +308,7 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
     weights, tier = None, None
     if world > 1 and merge == "hot":
         tier = TierPlan(model.counts, n_walks_global * int(walks.shape[1]) / max(1, min(n_chunks, max(n_local, 1))), world,
-                        model.window, model.negative, model.device, every=hot_every_for(n_local, n_chunks, hot_every))
+                        model.window, model.negative, model.device, every=hot_every_for(n_local, n_chunks, hot_every, world))
         weights = tier.w_full
     every = tier.every if tier is not None else 1
     plan = chunk_plan(n_local, n_chunks * every)
@@ -352,7 +357,7 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
     if merge == "hot":
         n0 = int(shards[0][0].shape[0])
         tier = TierPlan(models[0].counts, n_walks_global * L / max(1, min(n_chunks, max(n0, 1))), G, models[0].window,
-                        models[0].negative, models[0].device, every=hot_every_for(n0, n_chunks, hot_every))
+                        models[0].negative, models[0].device, every=hot_every_for(n0, n_chunks, hot_every, G))
         weights = tier.w_full
     every = tier.every if tier is not None else 1
     plans = [chunk_plan(int(w.shape[0]), n_chunks * every) for w, _, _ in shards]

@@ -262,8 +262,9 @@ def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, G):
         b, e = sgns.shard_bounds(n, G, r)
         idx = (torch.arange(rounds, device="cuda")[:, None] * n + torch.arange(b, e, device="cuda")[None, :]).reshape(-1)
         shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
-    # hot_every=8: the hot tier is forced on ("auto" switches it off when launches would get this short)
-    n_syncs = sgns.train_simulated_replicas(models, shards, n_walks_global=corpus.walks.shape[0], hot_every=8)
+    # two replicas: the hot tier is forced on ("auto" switches it off when launches would get this short)
+    n_syncs = sgns.train_simulated_replicas(models, shards, n_walks_global=corpus.walks.shape[0],
+                                            hot_every=8 if G == 2 else "auto")
     torch.cuda.synchronize()
     for m in models[1:]:
         assert torch.equal(m.syn0, models[0].syn0) and torch.equal(m.syn1neg, models[0].syn1neg)

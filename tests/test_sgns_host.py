@@ -190,8 +190,9 @@ def test_tier_plan_selects_hub_rows_and_degenerates_without_them():
 
 def test_hot_tier_frequency_respects_launch_size():
     from n2v_hip import sgns
-    # C3 shapes: 10M walks per rank; 2 ranks -> 67 full merges, 8 ranks -> 1867
-    assert sgns.hot_every_for(10_000_000, 67) == sgns.HOT_EVERY
-    assert sgns.hot_every_for(10_000_000, 400) == 3
-    assert sgns.hot_every_for(10_000_000, 1867) == 1          # the full interval is already below one launch
-    assert sgns.hot_every_for(25_000, 234) == 1 and sgns.hot_every_for(25_000, 234, 8) == 8
+    # C3 shapes: 10M walks per rank; 2 ranks -> 34 full merges
+    assert sgns.auto_syncs(20_000_000 * 80, 1_000_000, 2) == 34
+    assert sgns.hot_every_for(10_000_000, 34, world=2) == sgns.HOT_EVERY
+    assert sgns.hot_every_for(10_000_000, 400, world=2) == 3
+    assert sgns.hot_every_for(10_000_000, 34, world=8) == 1          # measured not to help reliably beyond 2 replicas
+    assert sgns.hot_every_for(25_000, 117, world=2) == 1 and sgns.hot_every_for(25_000, 117, 8, world=8) == 8
