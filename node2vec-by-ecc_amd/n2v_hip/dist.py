@@ -61,6 +61,10 @@ class _Comm(sgns._ProcessGroupComm):
     def __init__(self, host_staged):
         super().__init__()
         self.host_staged = host_staged
+        # over RCCL the replicas' changes travel as bfloat16 (half the bytes of every merge); the gloo rehearsal
+        # path stays fp32
+        self.wire_dtype = None if host_staged else torch.bfloat16
+        self.wire_dtype_f64 = None if host_staged else torch.float32   # BiNE's fp64 tables: changes as fp32
 
     def all_reduce_sum(self, t):
         if self.host_staged:

@@ -145,6 +145,7 @@ class SgnsModel:
 
 class _ProcessGroupComm:
     """torch.distributed all-reduce (RCCL on GPUs, gloo in the CPU tests)."""
+    wire_dtype = None   # dtype the replicas' changes travel in (None: the tables themselves, fp32)
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -172,7 +173,19 @@ def merge_replicas(tables, bases, comm, mode="hot", weights=None):
                  replica hammers (hubs, frequent negatives) get their MEAN — summing those
                  overshoots by a factor `world`, averaging cold rows under-trains them by it.
     mode 'delta': w_row = 1 (pure sum).   mode 'avg': w_row = 1/world (local SGD)."""
+    wire = getattr(comm, "wire_dtype", None)
     for i, (t, b) in enumerate(zip(tables, bases)):
+        if wire is not None and mode in ("hot", "delta"):
+            # the replicas' CHANGES travel, as `wire` (bfloat16 over RCCL: half the bytes; AUC unchanged to 1e-4 on
+            # both probe graphs, profiles/r01/logs/replica_bf16_*.log)
+            d = (t - b).to(wire)
+            comm.all_reduce_sum(d)
+            d = d.to(t.dtype)
+            if mode == "hot":
+                d.mul_(weights[i][:, None])
+            torch.add(b, d, out=t)
+            b.copy_(t)
+            continue
         comm.all_reduce_sum(t)
         if mode == "avg":
             t.div_(comm.world)
@@ -244,10 +257,16 @@ def merge_hot_rows(tables, bases, comm, plan):
     for t, b, rows, w in zip(tables, bases, plan.rows, plan.w_rows):
         if rows.numel() == 0:
             continue
-        x = t.index_select(0, rows)
-        comm.all_reduce_sum(x)
+        wire = getattr(comm, "wire_dtype", None)
         bb = b.index_select(0, rows)
-        x.sub_(bb, alpha=comm.world).mul_(w[:, None]).add_(bb)
+        if wire is not None:
+            x = (t.index_select(0, rows) - bb).to(wire)
+            comm.all_reduce_sum(x)
+            x = x.to(t.dtype).mul_(w[:, None]).add_(bb)
+        else:
+            x = t.index_select(0, rows)
+            comm.all_reduce_sum(x)
+            x.sub_(bb, alpha=comm.world).mul_(w[:, None]).add_(bb)
         t.index_copy_(0, rows, x)
         b.index_copy_(0, rows, x)
 

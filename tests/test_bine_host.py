@@ -218,3 +218,26 @@ def test_bine_engine_has_no_cpu_fallback():
     from n2v_hip import bine
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         bine.BineEngine(small_graph())
+
+
+def test_bine_replica_merge_with_fp32_wire():
+    import types
+    import torch
+    from n2v_hip import bine
+
+    class TwoIdenticalReplicas:
+        world, wire_dtype_f64 = 2, torch.float32
+
+        def all_reduce_sum(self, t):
+            t.mul_(2)
+
+    base = torch.arange(12, dtype=torch.float64).reshape(3, 4)
+    eng = types.SimpleNamespace(emb=base.clone(), ctx=base.clone(), state=torch.zeros(8, dtype=torch.float64))
+    m = bine.ReplicaMerge(eng, TwoIdenticalReplicas())
+    eng.emb += 1e-3
+    eng.ctx[1] -= 0.25
+    eng.state[1] = -2.0
+    m(eng)
+    assert torch.allclose(eng.emb, base + 2e-3, rtol=0, atol=1e-9) and eng.emb.dtype == torch.float64
+    want = base.clone(); want[1] -= 0.5
+    assert torch.equal(eng.ctx, want) and eng.state[1].item() == -4.0

@@ -196,3 +196,32 @@ def test_hot_tier_frequency_respects_launch_size():
     assert sgns.hot_every_for(10_000_000, 400, world=2) == 3
     assert sgns.hot_every_for(10_000_000, 34, world=8) == 1          # measured not to help reliably beyond 2 replicas
     assert sgns.hot_every_for(25_000, 117, world=2) == 1 and sgns.hot_every_for(25_000, 117, 8, world=8) == 8
+
+
+def test_merge_with_bf16_wire_format():
+    """Changes sent as bfloat16: base + w * sum_r bf16(t_r - base), for the full merge and the hot-tier merge."""
+    import torch
+    from n2v_hip import sgns
+
+    class TwoIdenticalReplicas:
+        world, wire_dtype = 2, torch.bfloat16
+
+        def all_reduce_sum(self, t):
+            assert t.dtype == torch.bfloat16
+            t.mul_(2)
+
+    comm = TwoIdenticalReplicas()
+    g = torch.Generator().manual_seed(0)
+    base = torch.randn(6, 8, generator=g)
+    t = base + 0.01 * torch.randn(6, 8, generator=g)
+    w = torch.tensor([1.0, 1.0, 0.5, 0.5, 0.75, 1.0])
+    want = base + w[:, None] * ((t - base).bfloat16() * 2).float()
+    tt, bb = t.clone(), base.clone()
+    sgns.merge_replicas([tt], [bb], comm, "hot", [w])
+    assert torch.allclose(tt, want, rtol=0, atol=1e-7) and torch.equal(bb, tt)
+    assert (tt - (base + w[:, None] * 2 * (t - base))).abs().max() < 2e-4      # bf16 rounding of the change only
+    plan = type("P", (), {})()
+    plan.rows, plan.w_rows = [torch.tensor([1, 4])], [w[[1, 4]]]
+    tt, bb = t.clone(), base.clone()
+    sgns.merge_hot_rows([tt], [bb], comm, plan)
+    assert torch.allclose(tt[[1, 4]], want[[1, 4]], atol=1e-7) and torch.equal(tt[[0, 2, 3, 5]], t[[0, 2, 3, 5]])

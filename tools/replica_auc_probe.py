@@ -42,7 +42,7 @@ def simulate(G, corpus, n_nodes, rounds, merge, syncs, mode="atomic"):
             if merge.startswith("hot"):
                 # per-row interpolation between sum (cold rows) and mean (hot rows) by the expected
                 # number of updates the row receives per replica and interval
-                B = float(merge[3:] or 16)
+                B = float(merge[3:].replace("bf16", "") or 16)
                 T = n_global * 80.0 / syncs
                 pv = counts.double() / counts.sum()
                 pn = counts.double() ** 0.75
@@ -50,7 +50,14 @@ def simulate(G, corpus, n_nodes, rounds, merge, syncs, mode="atomic"):
                 U = 10.5 * T * (pv if ti == 0 else (pv + 5 * pn))
                 lam = torch.clamp(B / ((G - 1) * U / G).clamp_min(1e-30), max=1.0).float()
                 w = lam + (1 - lam) / G
-                new = bases[ti] + (stack - bases[ti][None]).sum(0) * w[:, None]
+                if merge.endswith("bf16"):   # deltas travel and are summed as bfloat16 (ring all-reduce in bf16)
+                    dl = (stack - bases[ti][None]).bfloat16()
+                    acc = dl[0]
+                    for r in range(1, G):
+                        acc = acc + dl[r]
+                    new = bases[ti] + acc.float() * w[:, None]
+                else:
+                    new = bases[ti] + (stack - bases[ti][None]).sum(0) * w[:, None]
             elif merge == "avg":
                 new = stack.mean(0)
             elif merge == "delta":
