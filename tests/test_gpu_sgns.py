@@ -320,3 +320,47 @@ def test_main_link_flow_with_user_edges(torch_cuda):
     agree = sum(1 for a, b in zip(got, [(x[0], x[1]) for x in want]) if a == b) / max(len(want), 1)
     assert len(got) == len(want) and agree > 0.999   # fp32 GEMM vs per-pair dot: only near-ties may swap
     print("user edges: %d added, AUC %.4f -> %.4f" % (res["edges_added"], res["roc"], res["roc_user"]))
+
+
+def test_rccl_path_of_the_merges_single_rank(torch_cuda):
+    """The exact calls the multi-GPU merges make over RCCL (bf16 / fp32 wire formats, gathered hot rows), on a
+    one-rank process group: what the collective returns for one rank is its input, so the results are known."""
+    torch = torch_cuda
+    import os
+    import torch.distributed as dist
+    from n2v_hip import bine, sgns
+    from n2v_hip import dist as n2v_dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        comm = n2v_dist._Comm(False)
+        assert comm.world == 1 and comm.wire_dtype == torch.bfloat16 and comm.wire_dtype_f64 == torch.float32
+        g = torch.Generator(device="cuda").manual_seed(1)
+        base = torch.randn(64, 128, device="cuda", generator=g)
+        t = base + 0.01 * torch.randn(64, 128, device="cuda", generator=g)
+        w = torch.full((64,), 0.5, device="cuda")
+        want = base + 0.5 * (t - base).bfloat16().float()
+        tt, bb = t.clone(), base.clone()
+        sgns.merge_replicas([tt], [bb], comm, "hot", [w])
+        assert torch.allclose(tt, want, atol=1e-7) and torch.equal(bb, tt)
+        plan = type("P", (), {})()
+        plan.rows, plan.w_rows = [torch.tensor([3, 9], device="cuda")], [w[[3, 9]]]
+        tt, bb = t.clone(), base.clone()
+        sgns.merge_hot_rows([tt], [bb], comm, plan)
+        assert torch.allclose(tt[[3, 9]], want[[3, 9]], atol=1e-7) and torch.equal(tt[:3], t[:3])
+        import types
+        b64 = base.double()
+        eng = types.SimpleNamespace(emb=b64.clone(), ctx=b64.clone(), state=torch.zeros(8, dtype=torch.float64, device="cuda"))
+        m = bine.ReplicaMerge(eng, comm)
+        eng.emb += 1e-3
+        eng.state[1] = -3.0
+        m(eng)
+        assert torch.allclose(eng.emb, b64 + 1e-3, atol=1e-9) and torch.equal(eng.ctx, b64) and eng.state[1].item() == -3.0
+        counts = torch.ones(10, dtype=torch.int64, device="cuda")
+        comm.all_reduce_sum(counts)
+        assert int(counts.sum()) == 10
+    finally:
+        dist.destroy_process_group()
