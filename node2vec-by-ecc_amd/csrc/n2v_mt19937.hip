@@ -136,8 +136,8 @@ void mulmod(const Poly& a, const Poly& b, Poly& r) {
     r.assign(t.begin(), t.begin() + kPW);
 }
 
-// x^n mod M
-Poly powmod_x(uint64_t n) {
+// x^n mod M by square-and-multiply (any n)
+Poly powmod_x_generic(uint64_t n) {
     Poly r(kPW, 0), t;
     r[0] = 1;
     if (n == 0) return r;
@@ -161,6 +161,33 @@ Poly powmod_x(uint64_t n) {
     }
     return r;
 }
+
+// The family x^(624 * 2^m) mod M, m = 0, 1, 2, ...: every whole-block jump is a product of members (one per set
+// bit of the block count), and the doubling scheme of n2v_mt19937_jump_device with a stride of 624 * 2^k words
+// uses members k, k+1, ... directly — so after the first ~40 squarings (0.5 ms each) no call computes a
+// polynomial power again.
+struct Family {
+    std::vector<Poly> p;
+    std::mutex mu;
+};
+Family g_fam;
+
+Poly family_member(int m) {
+    std::lock_guard<std::mutex> lk(g_fam.mu);
+    Poly t;
+    while ((int)g_fam.p.size() <= m) {
+        if (g_fam.p.empty()) {
+            g_fam.p.push_back(powmod_x_generic((uint64_t)kN));
+        } else {
+            mulmod(g_fam.p.back(), g_fam.p.back(), t);
+            g_fam.p.push_back(t);
+        }
+    }
+    return g_fam.p[m];
+}
+
+// x^n mod M
+Poly powmod_x(uint64_t n) { return powmod_x_generic(n); }
 
 // out = g(A) in  (Horner); windows as 624 logical words
 // A^i w is words i..i+623 of the sequence x that continues w, so (g(A) w)[j] = XOR over the
@@ -329,6 +356,22 @@ extern "C" int n2v_mt19937_jump_host(const uint32_t* key_host, int64_t stride_wo
     if (!g_mt.ready) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_host: minimal polynomial not found");
     std::memcpy(states_host, key_host, sizeof(uint32_t) * kN);
     if (n_streams == 1) return N2V_OK;
+    if (stride_words > 0 && stride_words % kN == 0) {
+        // whole blocks: apply the family members of the set bits of the block count one after another
+        // (0.5 ms each) instead of raising x to a new power
+        uint32_t tmp[kN];
+        for (int k = 1; k < n_streams; ++k) {
+            uint32_t* cur = states_host + (size_t)k * kN;
+            std::memcpy(cur, states_host + (size_t)(k - 1) * kN, sizeof(uint32_t) * kN);
+            uint64_t blocks = (uint64_t)(stride_words / kN);
+            for (int m = 0; blocks; ++m, blocks >>= 1)
+                if (blocks & 1ULL) {
+                    apply_poly(family_member(m), cur, tmp);
+                    std::memcpy(cur, tmp, sizeof(tmp));
+                }
+        }
+        return N2V_OK;
+    }
     // jump polynomials of the last few strides (a walk alternates between the per-stream stride
     // and the whole-batch stride that moves numpy's global state)
     static std::mutex cache_mu;
@@ -362,14 +405,21 @@ extern "C" int n2v_mt19937_jump_polys_host(int64_t stride_words, int32_t n_round
         return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_polys_host: bad argument");
     build_modulus();
     if (!g_mt.ready) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_jump_polys_host: minimal polynomial not found");
-    Poly g = powmod_x((uint64_t)stride_words), t;
+    // a stride of 624 * 2^k words: the rounds' polynomials are family members k, k+1, ...
+    int fam_k = -1;
+    if (stride_words % kN == 0) {
+        const uint64_t blocks = (uint64_t)(stride_words / kN);
+        if ((blocks & (blocks - 1)) == 0) fam_k = __builtin_ctzll(blocks);
+    }
+    Poly g = fam_k >= 0 ? family_member(fam_k) : powmod_x((uint64_t)stride_words), t;
     for (int r = 0; r < n_rounds; ++r) {
+        if (fam_k >= 0 && r > 0) g = family_member(fam_k + r);
         uint32_t* row = polys_host + (size_t)r * kPosRow;
         uint32_t n = 0;
         for (int i = 0; i < kModDeg; ++i)
             if (pbit(g, i)) row[++n] = (uint32_t)i;
         row[0] = n;
-        if (r + 1 < n_rounds) {
+        if (fam_k < 0 && r + 1 < n_rounds) {
             mulmod(g, g, t);
             g.swap(t);
         }
