@@ -290,9 +290,13 @@ def auto_syncs(tokens_global, n_words, world):
     return max(1, int(np.ceil(tokens_global * (world - 1) / (STALENESS_BUDGET * max(n_words, 1)))))
 
 
-def chunk_plan(n_local, n_chunks):
-    """[begin, end) of every merge interval of a pass over n_local sentences."""
-    n_chunks = max(1, min(int(n_chunks), max(n_local, 1)))
+def chunk_plan(n_local, n_chunks, exact=False):
+    """[begin, end) of every merge interval of a pass over n_local sentences.  exact=True keeps exactly
+    n_chunks intervals (some may be empty): every rank must run the same number of collectives even when the
+    shards differ in size."""
+    n_chunks = max(1, int(n_chunks))
+    if not exact:
+        n_chunks = min(n_chunks, max(n_local, 1))
     return [shard_bounds(n_local, n_chunks, c) for c in range(n_chunks)]
 
 
@@ -324,13 +328,19 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
         bases = [model.syn0.clone(), model.syn1neg.clone()] if merge != "avg" else [None, None]
         n_chunks = (auto_syncs(n_walks_global * int(walks.shape[1]), model.n_words, world)
                     if syncs_per_epoch == "auto" else int(syncs_per_epoch))
-    weights, tier = None, None
+    # everything that decides how many collectives run must be the same on every rank: derived from the global
+    # walk count, never from this rank's shard size
+    per_rank = max(1, n_walks_global // world)
+    n_chunks = max(1, min(n_chunks, per_rank))
+    weights, tier, every = None, None, 1
     if world > 1 and merge == "hot":
-        tier = TierPlan(model.counts, n_walks_global * int(walks.shape[1]) / max(1, min(n_chunks, max(n_local, 1))), world,
-                        model.window, model.negative, model.device, every=hot_every_for(n_local, n_chunks, hot_every, world))
-        weights = tier.w_full
-    every = tier.every if tier is not None else 1
-    plan = chunk_plan(n_local, n_chunks * every)
+        every = hot_every_for(per_rank, n_chunks, hot_every, world)
+        if n_chunks * every > per_rank:
+            every = 1
+        tier = TierPlan(model.counts, n_walks_global * int(walks.shape[1]) / n_chunks, world, model.window,
+                        model.negative, model.device, every=every)
+        weights, every = tier.w_full, tier.every
+    plan = chunk_plan(n_local, n_chunks * every, exact=world > 1)
     for ep in range(epochs):
         for i, (b, e) in enumerate(plan):
             if e > b:
@@ -372,14 +382,17 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
     n_chunks = (auto_syncs(n_walks_global * L, models[0].n_words, G) if syncs_per_epoch == "auto"
                 else int(syncs_per_epoch))
     bases = [[m.syn0.clone(), m.syn1neg.clone()] if merge != "avg" else [None, None] for m in models]
-    weights, tier = None, None
+    per_rank = max(1, n_walks_global // G)
+    n_chunks = max(1, min(n_chunks, per_rank))
+    weights, tier, every = None, None, 1
     if merge == "hot":
-        n0 = int(shards[0][0].shape[0])
-        tier = TierPlan(models[0].counts, n_walks_global * L / max(1, min(n_chunks, max(n0, 1))), G, models[0].window,
-                        models[0].negative, models[0].device, every=hot_every_for(n0, n_chunks, hot_every, G))
-        weights = tier.w_full
-    every = tier.every if tier is not None else 1
-    plans = [chunk_plan(int(w.shape[0]), n_chunks * every) for w, _, _ in shards]
+        every = hot_every_for(per_rank, n_chunks, hot_every, G)
+        if n_chunks * every > per_rank:
+            every = 1
+        tier = TierPlan(models[0].counts, n_walks_global * L / n_chunks, G, models[0].window, models[0].negative,
+                        models[0].device, every=every)
+        weights, every = tier.w_full, tier.every
+    plans = [chunk_plan(int(w.shape[0]), n_chunks * every, exact=True) for w, _, _ in shards]
     total = epochs * n_walks_global
     for ep in range(epochs):
         for c in range(len(plans[0])):

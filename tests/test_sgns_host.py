@@ -49,6 +49,9 @@ def test_auto_syncs_and_chunk_plan():
     plan = chunk_plan(1001, 16)
     assert plan[0][0] == 0 and plan[-1][1] == 1001 and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
     assert len(chunk_plan(5, 100)) == 5 and chunk_plan(0, 4) == [(0, 0)]
+    # exact: the same number of intervals on every rank, empty ones included, covering the shard exactly once
+    p5 = chunk_plan(5, 8, exact=True)
+    assert len(p5) == 8 and sum(e - b for b, e in p5) == 5 and p5[-1][1] == 5 and len(chunk_plan(0, 3, exact=True)) == 3
 
 
 def test_merge_weights_limits():
