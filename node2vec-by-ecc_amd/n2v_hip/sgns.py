@@ -272,7 +272,7 @@ def merge_hot_rows(tables, bases, comm, plan):
 
 
 # Sync cadence.  Measured on one MI355X by training G simulated replicas
-# (tools/replica_auc_probe.py): on a 3000-node uniform graph (CPU comparator AUC 0.8961) the pure
+# (tests/probes/replica_auc_probe.py): on a 3000-node uniform graph (CPU comparator AUC 0.8961) the pure
 # sum ('delta') stays within 0.0005 while (G-1) * tokens per vocabulary row per interval is about
 # 12-22, is off by 0.0023 at 50 and diverges at 87.  On a 20k-node graph WITH hubs (comparator
 # 0.8672) no cadence rescues the pure sum (+0.006 at G=2, +0.020 at G=8: hub rows overshoot) nor

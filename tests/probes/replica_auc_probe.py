@@ -4,7 +4,7 @@ simulated on ONE GPU by training the replicas' chunks one after another."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "node2vec-by-ecc_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -124,3 +124,12 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.lower() or f == "__never__", os.path.join(dp, f)
+
+
+def test_tools_never_import_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/: the measurement scripts that need the
+    CPU comparator live under tests/probes/."""
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert "oracle" not in txt, f
