@@ -4,8 +4,10 @@
 (:225-240), `save_to_file` / `ndarray_tostring` (:519-531), `top_N` and its metrics (:311-406) and the argument
 defaults of `parser()` (:533-597).  The per-vertex dicts the reference returns
 (`node_list_u[u]['embedding_vectors']`, shape (1, d)) are views over the device tables copied back once.
-Out of scope here: the add-user-edges re-training of `main()` (:614-622; it only changes the HITS input —
-edge_list and the projections are not rebuilt there) — n2v_hip/augment.py has the selection kernels.
+`add_user_edge` + `run` reproduce `main()`'s second stage (:614-622): user-user similarity edges (all-pairs
+cosine of the user embeddings, selection by ratio / step / relu / relu-ratio / linear on the device,
+n2v_hip/augment.py) are added to the graph and `train` runs again — in the reference that changes the HITS input only
+(edge_list and the projections are not rebuilt there), and so it does here.
 """
 import argparse
 import math
@@ -73,6 +75,32 @@ def train(args, gul, mode="parallel"):
 
 
 train.last = {}
+
+
+def add_user_edge(args, gul, sim_method="cos", by_matrix=True):
+    """src/bine_train.py:160-181 + :620: similarity edges between users, added to the graph hits() sees.
+    Returns the number of distinct user pairs added.  Only the cosine similarity is built on the device;
+    'pearson' / 'jsd' (:68-71) raise."""
+    if sim_method != "cos":
+        raise NotImplementedError("sim_method %r: only 'cos' runs on the device" % (sim_method,))
+    from n2v_hip import augment
+    eng = gul.engine
+    vec = eng.emb[: gul.graph.n_u, : eng.dim]
+    s, d, w = augment.add_edges(vec, args.user_edges_mode, args.user_edges_ratio, args.user_edges_thre)
+    return eng.add_user_edges(s.cpu().numpy(), d.cpu().numpy(), w.cpu().numpy().astype(np.float64))
+
+
+def run(args, gul, mode="parallel"):
+    """main() after construct_training_graph (src/bine_train.py:612-622): train, then — with args.add_user_edges —
+    add the similarity edges and train again."""
+    node_list_u, roc, ap = train(args, gul, mode)
+    first = dict(train.last)
+    if args.add_user_edges:
+        n_added = add_user_edge(args, gul, sim_method=args.sim_method, by_matrix=False)
+        node_list_u, roc, ap = train(args, gul, mode)
+        train.last["user_edges_added"] = n_added
+        train.last["first_stage"] = first
+    return node_list_u, roc, ap
 
 
 def ndarray_tostring(array):

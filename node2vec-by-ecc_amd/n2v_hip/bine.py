@@ -164,6 +164,37 @@ class BineEngine:
     def _seed(self, k):
         return derive_seed(self.seed, k)
 
+    # ------------------------------------------------------------------ user-user edges (HITS input only)
+    def add_user_edges(self, src_user, dst_user, weight):
+        """`gul.G.add_weighted_edges_from(add_edges)` of src/bine_train.py:620: weighted user-user edges join the
+        networkx graph that calculate_centrality() hands to hits().  Nothing else of the pipeline reads them
+        (the projections come from the biadjacency of node_u x node_v, :114; edge_list / edge_dict_u are not
+        rebuilt), so only the HITS matrix changes.  Edges are applied in order; a repeated unordered pair keeps
+        its last weight (networkx semantics).  src_user / dst_user: user indices (0..n_u-1)."""
+        g = self.g
+        a = np.asarray(src_user, dtype=np.int64)
+        b = np.asarray(dst_user, dtype=np.int64)
+        w = np.asarray(weight, dtype=np.float64)
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        key = lo * g.n + hi
+        _, last_rev = np.unique(key[::-1], return_index=True)
+        win = len(key) - 1 - last_rev
+        lo, hi, w = lo[win], hi[win], w[win]
+        loop = lo == hi
+        src = np.concatenate([np.repeat(np.arange(g.n), np.diff(g.row_ptr)), lo, hi[~loop]])
+        dst = np.concatenate([g.col.astype(np.int64), hi, lo[~loop]])
+        ww = np.concatenate([g.w, w, w[~loop]])
+        o = np.lexsort((dst, src))
+        rp = np.zeros(g.n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(src, minlength=g.n), out=rp[1:])
+        d = self.device
+        self.hits_csr = (torch.from_numpy(rp).to(d), torch.from_numpy(dst[o].astype(np.int32)).to(d),
+                         torch.from_numpy(ww[o]).to(d))
+        self.authority = None
+        return int(len(lo))
+
+    hits_csr = None  # (row_ptr, col, w) of the graph handed to hits() when user-user edges were added
+
     # ------------------------------------------------------------------ centrality
     def calculate_centrality(self, max_iter=100, tol=1.0e-8):
         """nx.hits(G) of networkx 1.11 (src/bine_graph_utils.py:61): authority scores by power iteration from
@@ -175,9 +206,10 @@ class BineEngine:
             a = torch.empty_like(h)
             st = torch.zeros(1, dtype=torch.float64, device=d)
             p = _lib.ptr
+            rp, col, w = self.hits_csr if self.hits_csr is not None else (self.row_ptr, self.col, self.w)
             for it in range(max_iter):
-                _lib.check(lib.n2v_bine_spmv(n, p(self.row_ptr), p(self.col), p(self.w), p(h), p(a), self._stream()))
-                _lib.check(lib.n2v_bine_spmv(n, p(self.row_ptr), p(self.col), p(self.w), p(a), p(hn), self._stream()))
+                _lib.check(lib.n2v_bine_spmv(n, p(rp), p(col), p(w), p(h), p(a), self._stream()))
+                _lib.check(lib.n2v_bine_spmv(n, p(rp), p(col), p(w), p(a), p(hn), self._stream()))
                 _lib.check(lib.n2v_bine_hits_normalise(n, p(hn), p(a), p(h), p(st), self._stream()))
                 h, hn = hn, h
                 if float(st.item()) < tol:

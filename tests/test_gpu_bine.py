@@ -351,3 +351,37 @@ def test_config5_size_properties():
     b = e.train(max_iter=2, mode="store")
     assert e.mode_used == "store" and np.allclose(a, b, rtol=1e-3)
     assert torch.isfinite(e.emb).all() and torch.isfinite(e.ctx).all() and (e.emb[:, 256:].numel() == 0)
+
+
+def test_add_user_edges_changes_only_the_hits_input(tmp_path):
+    """main()'s second stage (src/bine_train.py:614-622): similarity edges between users join the graph hits()
+    sees; authority scores equal the networkx-1.11 restatement on that augmented graph; walks still move on the
+    bipartite projections."""
+    import bine_train as bt
+    from n2v_hip import bine
+    g = make_graph(seed=9, n_u=150, n_v=60, per_user=5)
+    gul = bt.GraphUtils(str(tmp_path), device="cuda:0", seed=4)
+    gul.graph = g
+    gul.engine = bine.BineEngine(g, device="cuda:0", seed=4)
+    args = bt.default_args(d=16, max_iter=3, maxT=4, user_edges_mode="ratio", user_edges_ratio=0.05)
+    bt.run(args, gul)
+    eng = gul.engine
+    n_added = bt.train.last["user_edges_added"]
+    k = int(g.n_u * 0.05)
+    assert 0 < n_added <= g.n_u * k and "first_stage" in bt.train.last
+    rp, col, w = (t.cpu().numpy() for t in eng.hits_csr)
+    assert len(col) == len(g.col) + 2 * n_added - int(((np.repeat(np.arange(g.n), np.diff(rp)) == col)).sum())
+    uu = (np.repeat(np.arange(g.n), np.diff(rp)) < g.n_u) & (col < g.n_u)
+    assert uu.sum() > 0 and (w[uu] == 1.0).all()
+    a, iters = bo.hits_nx111(rp, col, w)
+    assert eng.hits_iterations == iters and np.allclose(eng.authority.cpu().numpy(), a, rtol=1e-10, atol=1e-14)
+    a0, _ = bo.hits_nx111(g.row_ptr, g.col, g.w)
+    assert not np.allclose(a[: g.n_u] / a[: g.n_u].max(), a0[: g.n_u] / a0[: g.n_u].max(), atol=1e-3)
+    tok = eng.tokens.cpu().numpy()
+    off = eng.walk_off.cpu().numpy()
+    for i in range(0, eng.n_walks[0], 7):          # user walks: every step shares an ITEM
+        wlk = tok[off[i]:off[i + 1]]
+        for x, y in zip(wlk[:-1], wlk[1:]):
+            assert set(g.col[g.row_ptr[x]:g.row_ptr[x + 1]]) & set(g.col[g.row_ptr[y]:g.row_ptr[y + 1]])
+    with pytest.raises(NotImplementedError):
+        bt.add_user_edge(args, gul, sim_method="pearson")
