@@ -629,10 +629,11 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     const size_t shmem = (size_t)4 * a.lpad * sizeof(int32_t);
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks + 3) / 4;
-    // default grid: 256 CUs x 8 workgroups of 4 waves, but never more than one wave per two
-    // vocabulary rows — beyond that the racing waves read each other's rows so stale that
+    // default grid: 256 CUs x 12 workgroups of 4 waves — every wave slot of the chip at this kernel's 36-40
+    // VGPRs (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096 8.0e8, 6144 8.3e8) — but never more
+    // than one wave per two vocabulary rows — beyond that the racing waves read each other's rows so stale that
     // small graphs train measurably differently from the sequential algorithm
-    int64_t cap = max_blocks > 0 ? max_blocks : 2048;
+    int64_t cap = max_blocks > 0 ? max_blocks : 3072;
     if (max_blocks <= 0 && cap > n_words / 8) cap = n_words / 8 > 0 ? n_words / 8 : 1;
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);

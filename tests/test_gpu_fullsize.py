@@ -170,7 +170,7 @@ def test_auto_row_sharing_agrees_with_lossless_mode_at_200k(torch_cuda):
     torch = torch_cuda
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
     import node2vec
     from n2v_hip import csr, linkpred, sgns
     from replica_auc_probe import _hub_partition
