@@ -10,7 +10,6 @@ pure Python + gensim (src/main.py:66-101).  ``learn_embeddings`` reads the modul
 import argparse
 import os
 
-import numpy as np
 import torch
 
 import node2vec

@@ -16,7 +16,6 @@ tests/ check (P) == HIP exactly and (P) ~ (L) statistically (chi-square on next-
 distributions), so the chain reference-text -> (L) -> (P) -> HIP is closed without the reference running.
 """
 import math
-import random
 
 import numpy as np
 
