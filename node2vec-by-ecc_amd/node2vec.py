@@ -408,13 +408,14 @@ class Graph():
         # i.e. never on an undirected graph (every visited node has the edge it came by)
         may_end_early = bool(self._csr.directed) and bool((eng.deg == 0).any().item())
         if not may_end_early:
-            # every round consumes the same number of uniforms: stream them round-wise so
-            # the host never holds more than ~1 GiB of the MT19937 stream at a time
+            # every round consumes the same number of uniforms: stream them round-wise — at most ~4 GiB of the
+            # MT19937 stream in HBM at a time (1 GiB when numpy generates it on the host)
             per = int(per_round.sum().item())
             uoff_round = uoff[:n].contiguous()
             walks = torch.empty((W, L), dtype=torch.int32, device=d)
             lens = torch.empty(W, dtype=torch.int32, device=d)
-            rounds_per_chunk = max(1, min(num_walks, (1 << 27) // max(per, 1)))
+            budget = (1 << 27) if getattr(self, "host_rng", False) else (1 << 29)   # doubles
+            rounds_per_chunk = max(1, min(num_walks, budget // max(per, 1)))
             it = 0
             while it < num_walks:
                 k = min(rounds_per_chunk, num_walks - it)
