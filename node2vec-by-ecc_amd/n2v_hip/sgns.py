@@ -201,7 +201,8 @@ def merge_replicas(tables, bases, comm, mode="hot", weights=None):
 
 HOT_BUDGET = 256.0  # updates per replica and interval above which a row is merged towards the mean
 HOT_EVERY = 8       # merges of the hot tier per full merge
-MIN_WALKS_PER_LAUNCH = 8192  # one wavefront trains one walk at a time: shorter launches leave the chip idle
+MIN_WALKS_PER_LAUNCH = 8192  # one wavefront trains one walk at a time; launches of 5 356 walks still run at the
+                             # full-pass rate (tools/sgns_grid_probe.py), much shorter ones have not been measured
 HOT_TIER_FACTOR = 2.0  # a row is in the hot tier when its expected updates per full interval exceed this many budgets
 
 
