@@ -333,7 +333,7 @@ def test_rccl_path_of_the_merges_single_rank(torch_cuda):
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+    os.environ.setdefault("MASTER_PORT", str(29950 + os.getpid() % 40))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         comm = n2v_dist._Comm(False)
