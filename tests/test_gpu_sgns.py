@@ -332,8 +332,9 @@ def test_rccl_path_of_the_merges_single_rank(torch_cuda):
     from n2v_hip import dist as n2v_dist
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29950 + os.getpid() % 40))
+    had = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29950 + os.getpid() % 40)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         comm = n2v_dist._Comm(False)
@@ -364,3 +365,8 @@ def test_rccl_path_of_the_merges_single_rank(torch_cuda):
         assert int(counts.sum()) == 10
     finally:
         dist.destroy_process_group()
+        for k, v in had.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
