@@ -79,14 +79,15 @@ train.last = {}
 
 def add_user_edge(args, gul, sim_method="cos", by_matrix=True):
     """src/bine_train.py:160-181 + :620: similarity edges between users, added to the graph hits() sees.
-    Returns the number of distinct user pairs added.  Only the cosine similarity is built on the device;
-    'pearson' / 'jsd' (:68-71) raise."""
-    if sim_method != "cos":
-        raise NotImplementedError("sim_method %r: only 'cos' runs on the device" % (sim_method,))
+    Returns the number of distinct user pairs added.  sim_method 'cos' / 'pearson' / 'jsd' as :55-71 (all three
+    on the device, csrc/n2v_sim.hip; the scores are formed in fp32)."""
+    if sim_method not in ("cos", "pearson", "jsd"):
+        raise ValueError("sim_method %r" % (sim_method,))
     from n2v_hip import augment
     eng = gul.engine
     vec = eng.emb[: gul.graph.n_u, : eng.dim]
-    s, d, w = augment.add_edges(vec, args.user_edges_mode, args.user_edges_ratio, args.user_edges_thre)
+    s, d, w = augment.add_edges(vec, args.user_edges_mode, args.user_edges_ratio, args.user_edges_thre,
+                                sim_method=sim_method)
     return eng.add_user_edges(s.cpu().numpy(), d.cpu().numpy(), w.cpu().numpy().astype(np.float64))
 
 

@@ -86,6 +86,7 @@ def learn_embeddings(walks, **overrides):
         # and the learning-rate schedule are global, the replicas are merged over RCCL
         from n2v_hip import dist as _dist
         model.build_vocab(counts=_dist.global_counts(corpus.walks, len(corpus.labels), ctx))
+        assert model.device == ctx.device, "replica on %s but this rank owns %s" % (model.device, ctx.device)
         n_local = int(corpus.walks.shape[0])
         tot = torch.tensor([n_local], dtype=torch.int64, device=corpus.walks.device)
         ctx.comm.all_reduce_sum(tot)
@@ -102,25 +103,40 @@ def main(args_):
     '''
     global args
     args = args_
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx = None
+    if world > 1:
+        # one rank per GPU: bind this process to ITS device before anything is allocated, so graph, tables,
+        # walks and both embedding tables live on cuda:LOCAL_RANK (not all on cuda:0)
+        from n2v_hip import dist as _dist
+        ctx = _dist.RankContext()
     nx_G = read_graph()
     G = node2vec.Graph(nx_G, args.directed, args.p, args.q, rng=getattr(args, "rng", "numpy"),
-                       seed=getattr(args, "seed", 1))
+                       seed=getattr(args, "seed", 1), device=None if ctx is None else ctx.device)
     G.preprocess_transition_probs()
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if ctx is None:
         walks = G.simulate_walks(args.num_walks, args.walk_length)
         return learn_embeddings(walks)
-    # launched by torch.distributed.run, one rank per GPU: walks shard by start vertex, every
-    # rank ends with the same merged embedding (BASELINE config C4)
-    from n2v_hip import dist as _dist
-    ctx = _dist.RankContext()
+    # launched by torch.distributed.run: walks shard by start vertex, every rank ends with the same merged
+    # embedding (BASELINE config C4)
+    assert G._engine.device == ctx.device, (G._engine.device, ctx.device)
     walks = G.simulate_walks_shard(args.num_walks, args.walk_length, ctx.rank, ctx.world)
     emb = learn_embeddings(walks, ctx=ctx, n_starts=G._csr.n_nodes, num_walks=args.num_walks)
     ctx.barrier()
     return emb
 
 
+def save_embeddings(emb, path):
+    """src/main.py:88 writes args.output unconditionally; the directory is created if it is missing (the
+    reference would raise IOError after the whole run)."""
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    emb.wv.save_word2vec_format(path)
+
+
 if __name__ == "__main__":
     args = parse_args()
     emb = main(args)
-    if int(os.environ.get("RANK", "0")) == 0 and args.output and os.path.isdir(os.path.dirname(args.output) or "."):
-        emb.wv.save_word2vec_format(args.output)
+    if int(os.environ.get("RANK", "0")) == 0 and args.output:
+        save_embeddings(emb, args.output)

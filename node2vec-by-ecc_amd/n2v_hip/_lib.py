@@ -18,7 +18,7 @@ N2V_STATUS_ZERO_NORM = 1
 RNG_UNIFORMS = 0
 RNG_PHILOX = 1
 
-# name -> (restype, argtypes); mirrors include/n2v_hip.h and include/n2v_bine.h one to one
+# name -> (restype, argtypes); mirrors include/n2v_hip.h, n2v_bine.h and n2v_sim.h one to one
 _i64, _i32, _u64, _f64, _ptr = C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_void_p
 BINE_SEQUENTIAL = 0
 BINE_PARALLEL = 1
@@ -59,6 +59,14 @@ SIGNATURES = {
                                       _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _f64, _ptr, _i32, _u64, _u64,
                                       _i32, _i32, _ptr]),
     "n2v_bine_lambda_step": (C.c_int, [_ptr, _f64, _ptr]),
+    # include/n2v_sim.h
+    "n2v_sim_prepare": (C.c_int, [_ptr, _i32, _i32, _ptr, _i64, _i32, _ptr, _i32, _ptr]),
+    "n2v_sim_block": (C.c_int, [_ptr, _i64, _i64, _ptr, _i64, _i32, _i32, _i64, _ptr, _i64, _ptr]),
+    "n2v_sim_topk_scan": (C.c_int, [_ptr, _i64, _i64, _ptr, _i64, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr,
+                                    _i64, _ptr, _ptr]),
+    "n2v_sim_rows_count": (C.c_int, [_ptr, _i64, _i64, _i64, C.c_float, _ptr, _ptr]),
+    "n2v_sim_rows_fill": (C.c_int, [_ptr, _i64, _i64, _i64, C.c_float, _ptr, _ptr, _ptr, _ptr]),
+    "n2v_sim_rows_topk": (C.c_int, [_ptr, _i64, _i64, _i64, _i32, _ptr, _ptr, _ptr]),
 }
 
 _lib = None

@@ -2,20 +2,25 @@
 after a first embedding, connect every "user" node to the users most similar to it, then walk
 and embed again on the augmented, now weighted, graph.
 
-The reference fills an N_user x N_user cosine matrix with a Python double loop over
-``emb.similarity`` (:368-377) and sorts every row in Python (:379-453).  Here the rows are
-produced in blocks by one library GEMM on unit vectors (a plain dense product — rocBLAS through
-torch.mm, no custom kernel) and the per-row selection runs on the device; nothing of size N^2 is
-ever held at once.  Semantics kept from the reference: a user's similarity to itself counts as 0
+The reference fills an N_user x N_user similarity matrix with a Python double loop over
+``get_similarity`` (:358-377: "cos" = gensim similarity, "pearson" = scipy pearsonr, "jsd" = its js()) and
+sorts every row in Python (:379-453).  Here the tile kernel of csrc/n2v_sim.hip forms the scores of a block
+of users against all users once and one workgroup per user selects on the device — by threshold, or by an
+exact radix select of the int(N*ratio)-th largest score — so nothing of size N^2 is ever held.
+Semantics kept from the reference: a user's similarity to itself counts as 0
 (:386,:404) and is NOT excluded from the ranking; "ratio" keeps the int(N*ratio) most similar per
 user in descending order (ties in list order) with weight 1; "step" keeps similarity > threshold
 with weight 1; "relu" the same with weight = similarity; "relu-ratio" is "relu" with the ratio as
 its threshold (that is what :469 does); "linear" keeps every pair with weight = similarity.
+"jsd" is kept as the reference has it: a DIVERGENCE used as if it were a similarity, infinite whenever a
+vector has a negative component (scipy rel_entr) — i.e. for practically every learned embedding.
 PARITY UNPINNED: the reference's main_link.py does not import here (pathos, gensim), its output
 is pinned by no fixture; the tests compare against a plain-Python restatement of that text.
 """
 import numpy as np
 import torch
+
+from . import simsel
 
 ITEM_PREFIX = "9999999"  # item nodes are marked by this id prefix (src/utils.py:392, main_link.py:459)
 
@@ -29,45 +34,40 @@ def user_nodes(labels, unseparated=False):
     return labels[keep]
 
 
-def _unit(vectors):
-    v = vectors.to(torch.float32)
-    return v / v.norm(dim=1, keepdim=True).clamp_min(1e-30)
-
-
-def add_edges(vectors, mode="ratio", ratio=0.1, thre=0.5, block_rows=4096):
-    """vectors: float [n, d] (device or CPU) of the user nodes, in user_nodes order.
+def add_edges(vectors, mode="ratio", ratio=0.1, thre=0.5, block_rows=4096, sim_method="cos"):
+    """vectors: float [n, d] device tensor of the user nodes, in user_nodes order.
     Returns (src_idx, dst_idx, weight) tensors over user indices, in the reference's output order
     (user by user; inside a user: ranking order for "ratio", list order otherwise)."""
     n = int(vectors.shape[0])
-    xn = _unit(vectors)
-    dev = xn.device
+    X = simsel.prepare(vectors, sim_method)
+    dev = X.device
     if mode == "relu-ratio":
         mode, thre = "relu", ratio
+    if mode not in ("ratio", "step", "relu", "linear"):
+        raise ValueError("user-edges-mode value fault: " + str(mode))
     k = int(n * ratio)
     srcs, dsts, ws = [], [], []
+    block_rows = max(1, min(int(block_rows), (1 << 31) // max(n, 1)))   # score block <= 8 GiB
     for b in range(0, n, block_rows):
         e = min(n, b + block_rows)
-        sim = xn[b:e] @ xn.T                                    # cosine of unit vectors
+        sim = simsel.score_block(X, b, e - b, X, sim_method, zero_diag_off=0)   # user_user_sim_list[i] = 0
         rows = torch.arange(b, e, device=dev)
-        sim[rows - b, rows] = 0.0                               # user_user_sim_list[i] = 0
         if mode == "ratio":
             if k == 0:
                 continue
-            order = torch.sort(sim, dim=1, descending=True, stable=True).indices[:, :k]
+            cols, _ = simsel.rows_topk(sim, n, k)
             srcs.append(rows[:, None].expand(-1, k).reshape(-1))
-            dsts.append(order.reshape(-1))
+            dsts.append(cols.reshape(-1).long())
             ws.append(torch.ones((e - b) * k, dtype=torch.float32, device=dev))
         elif mode in ("step", "relu"):
-            r, c = torch.nonzero(sim > thre, as_tuple=True)      # row-major = user by user, list order
+            r, c, v = simsel.rows_above(sim, n, thre)                # row-major = user by user, list order
             srcs.append(r + b)
-            dsts.append(c)
-            ws.append(torch.ones(r.numel(), dtype=torch.float32, device=dev) if mode == "step" else sim[r, c])
-        elif mode == "linear":
+            dsts.append(c.long())
+            ws.append(torch.ones(r.numel(), dtype=torch.float32, device=dev) if mode == "step" else v)
+        else:
             srcs.append(rows[:, None].expand(-1, n).reshape(-1))
             dsts.append(torch.arange(n, device=dev)[None, :].expand(e - b, -1).reshape(-1))
             ws.append(sim.reshape(-1))
-        else:
-            raise ValueError("user-edges-mode value fault: " + str(mode))
     if not srcs:
         z = torch.zeros(0, dtype=torch.int64, device=dev)
         return z, z.clone(), torch.zeros(0, dtype=torch.float32, device=dev)
@@ -110,11 +110,11 @@ def add_weighted_edges(graph, src, dst, w):
     return CsrGraph(graph.labels, row_ptr, b.astype(np.int32), ww, graph.start_order, graph.directed)
 
 
-def augment_graph(graph, vectors_by_dense, mode="ratio", ratio=0.1, thre=0.5, unseparated=False):
+def augment_graph(graph, vectors_by_dense, mode="ratio", ratio=0.1, thre=0.5, unseparated=False, sim_method="cos"):
     """src/main_link.py:568-573: user nodes -> similarity edges -> nx_G.add_weighted_edges_from.
     vectors_by_dense: float [N, d] tensor (row = dense node id).  Returns (new CsrGraph, #edges added)."""
     users = user_nodes(graph.labels[graph.start_order], unseparated)      # g.nodes() order
     u_dense = torch.as_tensor(graph.dense_of(users).astype(np.int64), device=vectors_by_dense.device)
-    s, d, w = add_edges(vectors_by_dense[u_dense], mode, ratio, thre)
+    s, d, w = add_edges(vectors_by_dense[u_dense], mode, ratio, thre, sim_method=sim_method)
     s, d, w = s.cpu().numpy(), d.cpu().numpy(), w.cpu().numpy().astype(np.float64)
     return add_weighted_edges(graph, users[s], users[d], w), len(s)

@@ -251,10 +251,15 @@ class WalkEngine:
                 lens = torch.empty(n_local, dtype=torch.int32, device=d)
             else:
                 walks, lens = out
-            if getattr(self, "_otf_scratch", None) is None and self.max_degree > 512:
-                n_waves = min(256 * 5 * 4, max(4, (n_local + 3) // 4 * 4))
-                self._otf_scratch = torch.empty((n_waves * self.max_degree, 2), dtype=torch.int64, device=d)
             scratch = getattr(self, "_otf_scratch", None)
+            if self.max_degree > 512:
+                # one scratch row per resident wavefront; grown when a later call launches more waves than the
+                # call that first allocated it (a single node2vec_walk_on_the_fly must not pin later launches
+                # to one workgroup)
+                n_waves = min(256 * 5 * 4, max(4, (n_local + 3) // 4 * 4))
+                if scratch is None or scratch.shape[0] < n_waves * self.max_degree:
+                    scratch = self._otf_scratch = torch.empty((n_waves * self.max_degree, 2), dtype=torch.int64,
+                                                              device=d)
             status = torch.zeros(1, dtype=torch.int32, device=d)
             mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
             _lib.check(self.lib.n2v_walk_on_the_fly(

@@ -1,8 +1,35 @@
-"""Link-prediction scoring on the device (src/main_link.py:43-61,173-204 of the reference,
-``link_method == "cos"``): batched cosine over edge lists and ROC-AUC / average precision by
-rank statistics, so a 10^7-edge evaluation does not go through a Python loop."""
+"""Link-prediction scoring on the device (src/main_link.py:43-204 of the reference): batched cosine over
+edge lists and ROC-AUC / average precision by rank statistics, so a 10^7-edge evaluation does not go through
+a Python loop; and the top-k prediction path (``link_prediction`` / ``precision_at_k`` / ``calculate_pop``,
+:62-170) on the tile + running-top-k kernels of csrc/n2v_sim.hip."""
 import numpy as np
 import torch
+
+ITEM_PREFIX = "9999999"   # item nodes carry this id prefix (src/utils.py:392; tested at src/main_link.py:118-121,135)
+KS = [1, 10, 50, 100, 500, 1000]   # default `ks` of link_prediction (src/main_link.py:123)
+
+
+def link_score(emb, a, b, link_method="cos"):
+    """src/main_link.py:43-60 on a KeyedVectors-like `emb`: "cos" -> float, "hadamard"/"avg" -> vectors (the
+    reference returns them although its own roc_auc_score call cannot take them), "weight1" -> euclidean
+    distance, "weight2" -> its square."""
+    if link_method == "cos":
+        try:
+            return emb.similarity(str(a), str(b))
+        except KeyError:
+            print("something's wrong. a:{}, b:{}".format(a, b))
+            return 0
+    x, y = emb[str(a)], emb[str(b)]
+    if link_method == "hadamard":
+        return np.multiply(x, y)
+    if link_method == "avg":
+        return (x + y) / 2.0
+    diff = x - y
+    if link_method == "weight1":
+        return np.sqrt(diff.dot(diff))
+    if link_method == "weight2":
+        return diff.dot(diff)
+    raise ValueError("link_method %r" % (link_method,))
 
 
 def cosine_scores(vectors, pairs):
@@ -141,3 +168,94 @@ def _with_isolated_nodes(train, full):
     np.cumsum(deg, out=row_ptr[1:])
     col = pos[train.col].astype(np.int32)   # rows stay sorted: pos is increasing
     return CsrGraph(full.labels, row_ptr, col, train.w, full.start_order, train.directed)
+
+
+# --------------------------------------------------------------------------- top-k prediction (:62-170)
+def _is_item(labels):
+    return np.array([str(int(x)).startswith(ITEM_PREFIX) for x in labels], dtype=bool)
+
+
+def precision_at_k(pred_k, test_edges):
+    """src/main_link.py:62-67: share of the predicted pairs that are test edges in either orientation."""
+    test = set((a, b) for a, b in test_edges)
+    count = 0.0
+    for pred in pred_k:
+        if tuple(pred) in test or (pred[1], pred[0]) in test:
+            count += 1
+    return count / len(pred_k)
+
+
+def calculate_pop(degrees_by_label, chosen_k_links, unseparated=False):
+    """src/main_link.py:110-120: "popularity" = len(g[node]) of the item end of a link (mean of both ends,
+    floored, when unseparated).  degrees_by_label: callable label -> degree in the training graph."""
+    pop = []
+    for a, b in chosen_k_links:
+        a, b = int(a), int(b)
+        if unseparated:
+            pop.append(int((degrees_by_label(a) + degrees_by_label(b)) // 2))
+        elif str(a).startswith(ITEM_PREFIX):
+            pop.append(degrees_by_label(a))
+        elif str(b).startswith(ITEM_PREFIX):
+            pop.append(degrees_by_label(b))
+    assert len(pop) == len(chosen_k_links)
+    return pop
+
+
+def link_prediction(vectors, graph, train_edges, test_edges, ks=KS, unseparated=False, vocab_mask=None,
+                    sim_method="cos"):
+    """src/main_link.py:123-170.  vectors: device float [N, >=d] indexed by dense id of `graph` (the training
+    CsrGraph: dense ids ascend with the label, i.e. the reference's `sorted(int(x) for x in emb.vocab)` order);
+    train_edges / test_edges: int arrays [M, 2] of labels.  Every (user, item) pair — or every pair
+    nodes[i], nodes[j], i < j, when `unseparated` — that is not a training edge IN THAT ORIENTATION (the
+    reference subtracts the tuples as they are, :74,:84) is scored on the device; the max(ks) best survive a
+    running threshold, so nothing of size users x items is stored.  The reference's `segment` batching only
+    bounds its memory: merging per-segment top-k lists and cutting at k again is the global top-k.
+    Returns (results, final_results) as the reference: results[k] = [((a, b), score, pop), ...] with string
+    ids, final_results[k] = (precision, avg_pop) — avg_pop floored like the reference's Python-2 division."""
+    from . import simsel
+    labels = graph.labels
+    n = len(labels)
+    in_vocab = np.ones(n, dtype=bool) if vocab_mask is None else np.asarray(vocab_mask, dtype=bool)
+    if unseparated:
+        rows = cols = np.nonzero(in_vocab)[0]
+    else:
+        item = _is_item(labels)
+        rows, cols = np.nonzero(in_vocab & ~item)[0], np.nonzero(in_vocab & item)[0]
+    dev = vectors.device
+    dim = int(vectors.shape[1])
+    A = simsel.prepare(vectors, sim_method, rows=torch.from_numpy(rows), dim=dim)
+    B = A if unseparated else simsel.prepare(vectors, sim_method, rows=torch.from_numpy(cols), dim=dim)
+    n_rows, n_cols = len(rows), len(cols)
+    # training edges, as ordered (row, col) keys
+    tr = np.asarray(train_edges, dtype=np.int64).reshape(-1, 2)
+    pos_r, pos_c = np.full(n, -1, dtype=np.int64), np.full(n, -1, dtype=np.int64)
+    pos_r[rows] = np.arange(n_rows)
+    pos_c[cols] = np.arange(n_cols)
+    known = np.isin(tr, labels).all(axis=1) if len(tr) else np.zeros(0, dtype=bool)
+    da, db = graph.dense_of(tr[known, 0]), graph.dense_of(tr[known, 1])
+    ok = (pos_r[da] >= 0) & (pos_c[db] >= 0)
+    keys = np.unique(pos_r[da[ok]] * n_cols + pos_c[db[ok]])
+    total = n_rows * (n_rows - 1) // 2 if unseparated else n_rows * n_cols
+    kmax = int(min(max(ks), max(total - len(keys), 0)))
+    if kmax == 0:
+        raise ValueError("link_prediction: no candidate pairs")
+    s, r, c = simsel.global_topk(A, B, kmax, sim_method, upper_triangle=unseparated,
+                                 exclude_keys=torch.from_numpy(keys).to(dev))
+    s, r, c = s.cpu().numpy(), rows[r.cpu().numpy()], cols[c.cpu().numpy()]
+    deg = np.diff(graph.row_ptr)
+    te = np.asarray(test_edges, dtype=np.int64).reshape(-1, 2)
+    te_known = np.isin(te, labels).all(axis=1) if len(te) else np.zeros(0, dtype=bool)
+    ta, tb = graph.dense_of(te[te_known, 0]), graph.dense_of(te[te_known, 1])
+    test_keys = np.unique(np.minimum(ta, tb) * n + np.maximum(ta, tb))
+    hit = np.isin(np.minimum(r, c).astype(np.int64) * n + np.maximum(r, c), test_keys)
+    item_mask = None if unseparated else _is_item(labels)
+    if unseparated:
+        pop = (deg[r] + deg[c]) // 2
+    else:
+        pop = np.where(item_mask[r], deg[r], deg[c])
+    results, final_results = {}, {}
+    for k in ks:
+        kk = min(k, len(s))
+        results[k] = [((str(int(labels[r[i]])), str(int(labels[c[i]]))), float(s[i]), int(pop[i])) for i in range(kk)]
+        final_results[k] = (float(hit[:kk].sum()) / kk, int(pop[:kk].sum()) // kk)
+    return results, final_results

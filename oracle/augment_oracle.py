@@ -13,8 +13,30 @@ def similarity(emb, a, b):
     return float(np.dot(x / np.linalg.norm(x), y / np.linalg.norm(y)))
 
 
+def js(p, q):                                                       # :351-356
+    from scipy.stats import entropy
+    p_norm = p / p.sum()
+    q_norm = q / q.sum()
+    m = (p_norm + q_norm) / 2
+    return (entropy(p_norm, m) + entropy(q_norm, m)) / 2
+
+
+def get_similarity(emb, user1, user2, sim_method="cos"):           # :358-365
+    if sim_method == "cos":
+        return similarity(emb, user1, user2)
+    if sim_method == "pearson":
+        from scipy.stats import pearsonr
+        return pearsonr(np.asarray(emb[user1]), np.asarray(emb[user2]))[0]
+    if sim_method == "jsd":
+        return js(np.asarray(emb[user1]), np.asarray(emb[user2]))
+    raise ValueError(sim_method)
+
+
+SIM_METHOD = "cos"   # the reference threads sim_method through every call; a module switch keeps the restatement short
+
+
 def _sim_list(emb, user_nodes, i, user):
-    lst = [similarity(emb, user, user2) for user2 in user_nodes]   # :385 / :403 / :420 / :437 / :453
+    lst = [get_similarity(emb, user, user2, SIM_METHOD) for user2 in user_nodes]   # :385 / :403 / :420 / :437 / :453
     lst[i] = 0
     return lst
 
@@ -51,7 +73,9 @@ def get_add_edge_linear(user_nodes, emb):                          # :442-453
     return add_edge
 
 
-def add_user_edge(user_nodes, emb, mode, ratio, thre):             # :455-475
+def add_user_edge(user_nodes, emb, mode, ratio, thre, sim_method="cos"):   # :455-475
+    global SIM_METHOD
+    SIM_METHOD = sim_method
     if mode == "ratio":
         return get_add_edge_by_ratio(user_nodes, ratio, emb)
     if mode == "step":

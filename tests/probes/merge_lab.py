@@ -1,0 +1,243 @@
+"""Round-2 lab: which replica-merge rule keeps G simulated replicas inside the +-0.002 AUC band of the sequential
+comparator on BOTH the hub graph and the uniform graph, at which cadence, and what a one-interval DELAYED merge
+(the schedule that lets the all-reduce run under the next interval's training) costs.  One GPU, replicas trained
+interval by interval.  Usage: python tests/probes/merge_lab.py <hub|pp|ba:20000> ; env GS, BUDGETS, RULES, DELAYS."""
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "node2vec-by-ecc_amd"), os.path.join(ROOT, "tests"), os.path.dirname(os.path.abspath(__file__))):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+
+import node2vec
+from n2v_hip import linkpred, sgns
+import replica_auc_probe as rap
+
+WINDOW, NEG, L = 10, 5, 80
+
+
+def expected_updates(counts, tokens_interval_global):
+    """Expected row updates per interval over ALL replicas: (syn0 rows, syn1neg rows)."""
+    c = counts.double()
+    pv = c / c.sum()
+    pn = c ** 0.75
+    pn = pn / pn.sum()
+    ppt = WINDOW + 0.5
+    return ppt * tokens_interval_global * pv, ppt * tokens_interval_global * (pv + NEG * pn)
+
+
+def rule_weights(rule, G, upd, alpha_now, r_opp, delay):
+    """Per-row weight on the SUM of the replicas' changes."""
+    kind, _, arg = rule.partition(":")
+    if kind == "sum":
+        return torch.ones_like(upd, dtype=torch.float32)
+    if kind == "mean":
+        return torch.full_like(upd, 1.0 / G, dtype=torch.float32)
+    if kind == "hot":
+        B = float(arg or 256)
+        u = (G - 1) / G * upd
+        lam = torch.clamp(B / u.clamp_min(1e-30), max=1.0)
+        return (lam + (1 - lam) / G).float()
+    if kind in ("exp", "expa"):
+        # linear-contraction model: one replica's n updates contract a row's error by c = exp(-h); G sequential
+        # blocks would contract it by c^G; weight on the sum = (1 - c^G) / (G (1 - c)).
+        kappa = float(arg)
+        n = upd / G * (1 + delay)
+        a = alpha_now if kind == "exp" else 0.025
+        h = (kappa * a * r_opp) * n
+        h = h.clamp_min(1e-9)
+        w = -torch.expm1(-G * h) / (G * -torch.expm1(-h))
+        return w.float()
+    raise ValueError(rule)
+
+
+def simulate_hybrid(G, corpus, n_nodes, rounds, syncs, rule, theta, mode="atomic", bf16=True):
+    """Two tiers.  HOT rows (expected updates by the other replicas per interval > theta) are merged at the end
+    of every interval with the weights of `rule` — a small message, sent synchronously.  COLD rows (the bulk of
+    the table) are merged ONE INTERVAL LATE: their changes of interval k are summed while interval k+1 trains
+    (this is the part that can travel under the next launch) and applied at its end."""
+    n = corpus.walks.shape[0] // rounds
+    dev = corpus.walks.device
+    models = [sgns.SgnsModel(n_nodes, dim=128, window=WINDOW, negative=NEG, seed=1, update_mode=mode) for _ in range(G)]
+    counts = torch.bincount(corpus.walks.reshape(-1).long(), minlength=n_nodes)
+    for m in models:
+        m.build_vocab(counts=counts)
+    shards = []
+    for r in range(G):
+        b, e = sgns.shard_bounds(n, G, r)
+        idx = (torch.arange(rounds, device=dev)[:, None] * n + torch.arange(b, e, device=dev)[None, :]).reshape(-1)
+        shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
+    n_global = corpus.walks.shape[0]
+    names = ("syn0", "syn1neg")
+    base = [getattr(models[0], nm).clone() for nm in names]
+    xs = [[getattr(m, nm).clone() for nm in names] for m in models]
+    upd = expected_updates(counts, n_global * float(L) / syncs)
+    hot = [((G - 1) / G * upd[ti]) > theta for ti in range(2)]
+    wts = [rule_weights(rule, G, upd[ti], 0.0, 0.0, 0) for ti in range(2)]
+    pending = None
+    for c in range(syncs):
+        for r, m in enumerate(models):
+            w, l, off = shards[r]
+            b, e = sgns.shard_bounds(w.shape[0], syncs, c)
+            if e > b:
+                m.train_pass(w[b:e], l[b:e], sentences_base=b * G, sentences_step=G, sentences_total=n_global,
+                             walk_id_base=off + b)
+        last = c + 1 == syncs
+        newS = []
+        for ti, nm in enumerate(names):
+            Ds = [getattr(m, nm) - xs[r][ti] for r, m in enumerate(models)]
+            S = torch.zeros_like(base[ti])
+            for d in Ds:
+                S += d.bfloat16().float() if bf16 else d
+            h = hot[ti]
+            # hot rows: at once
+            base[ti][h] += (S * wts[ti][:, None])[h]
+            # cold rows: what was sent one interval ago arrives now
+            if pending is not None:
+                base[ti][~h] += (pending[ti] * wts[ti][:, None])[~h]
+            if last:
+                base[ti][~h] += (S * wts[ti][:, None])[~h]
+            for r, m in enumerate(models):
+                x = getattr(m, nm)
+                x.copy_(base[ti])
+                if not last:
+                    x[~h] += Ds[r][~h]          # a replica keeps its own not-yet-merged cold changes
+                xs[r][ti].copy_(x)
+            newS.append(S)
+        pending = newS
+    frac = [float(h.float().mean()) for h in hot]
+    return models[0], frac
+
+
+def simulate(G, corpus, n_nodes, rounds, syncs, rule, delay=0, mode="atomic", bf16=True):
+    n = corpus.walks.shape[0] // rounds
+    dev = corpus.walks.device
+    models = [sgns.SgnsModel(n_nodes, dim=128, window=WINDOW, negative=NEG, seed=1, update_mode=mode) for _ in range(G)]
+    counts = torch.bincount(corpus.walks.reshape(-1).long(), minlength=n_nodes)
+    for m in models:
+        m.build_vocab(counts=counts)
+    shards = []
+    for r in range(G):
+        b, e = sgns.shard_bounds(n, G, r)
+        idx = (torch.arange(rounds, device=dev)[:, None] * n + torch.arange(b, e, device=dev)[None, :]).reshape(-1)
+        shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
+    n_global = corpus.walks.shape[0]
+    names = ("syn0", "syn1neg")
+    base = [getattr(models[0], nm).clone() for nm in names]
+    xs = [[getattr(m, nm).clone() for nm in names] for m in models]   # start-of-interval snapshots (delay mode)
+    upd = expected_updates(counts, n_global * float(L) / syncs)
+    live = counts > 0
+    pending = None
+    for c in range(syncs):
+        for r, m in enumerate(models):
+            w, l, off = shards[r]
+            b, e = sgns.shard_bounds(w.shape[0], syncs, c)
+            if e > b:
+                m.train_pass(w[b:e], l[b:e], sentences_base=b * G, sentences_step=G, sentences_total=n_global,
+                             walk_id_base=off + b)
+        alpha_now = 0.025 - (0.025 - 1e-4) * (c + 0.5) / syncs
+        # mean squared norm of the OPPOSITE table's rows (what a row's updates are made of)
+        r_sq = [float((base[1 - ti][live] ** 2).sum(1).mean()) for ti in range(2)]
+        wts = [rule_weights(rule, G, upd[ti], alpha_now, r_sq[ti], delay) for ti in range(2)]
+        if delay == 0:
+            for ti, nm in enumerate(names):
+                S = torch.zeros_like(base[ti])
+                for m in models:
+                    d = getattr(m, nm) - base[ti]
+                    S += d.bfloat16().float() if bf16 else d
+                base[ti] += S * wts[ti][:, None]
+                for m in models:
+                    getattr(m, nm).copy_(base[ti])
+        else:
+            Ds = [[getattr(m, nm) - xs[r][ti] for ti, nm in enumerate(names)] for r, m in enumerate(models)]
+            if pending is not None:
+                for ti in range(2):
+                    base[ti] += pending[0][ti] * pending[1][ti][:, None]
+            S = []
+            for ti in range(2):
+                s = torch.zeros_like(base[ti])
+                for r in range(G):
+                    s += Ds[r][ti].bfloat16().float() if bf16 else Ds[r][ti]
+                S.append(s)
+            last = c + 1 == syncs
+            if last:
+                for ti in range(2):
+                    base[ti] += S[ti] * wts[ti][:, None]
+            for r, m in enumerate(models):
+                for ti, nm in enumerate(names):
+                    x = getattr(m, nm)
+                    if last:
+                        x.copy_(base[ti])
+                    else:
+                        torch.add(base[ti], Ds[r][ti], out=x)
+                    xs[r][ti].copy_(x)
+            pending = (S, wts)
+    return models[0]
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "hub"
+    g, te, neg = rap.setup(kind)
+    Gr = node2vec.Graph.from_csr(g, 1.0, 1.0, rng="philox", seed=1)
+    Gr.preprocess_transition_probs()
+    rounds = 10
+    corpus = Gr.simulate_walks(rounds, L)
+    te_d = np.stack([g.dense_of(te[:, 0]), g.dense_of(te[:, 1])], 1)
+    neg_d = np.stack([g.dense_of(neg[:, 0]), g.dense_of(neg[:, 1])], 1)
+    from oracle import c_oracle
+    counts = np.bincount(corpus.walks.cpu().numpy().reshape(-1), minlength=g.n_nodes)
+    si, cum = sgns.vocab_tables(counts, 1e-3)
+    wk, ln = corpus.walks.cpu().numpy(), corpus.lens.cpu().numpy()
+    seq = {}
+
+    def run_seq():
+        syn0, syn1 = c_oracle.sgns_init(g.n_nodes, 128, 128, 1)
+        t = time.time()
+        c_oracle.sgns_train(wk, ln, syn0, syn1, 128, 10, 5, si, cum, n_threads=1)
+        seq["syn0"], seq["t"] = syn0, time.time() - t
+    th = None
+    if os.environ.get("SEQ", "1") == "1":
+        th = threading.Thread(target=run_seq)
+        th.start()
+    syn0, syn1 = c_oracle.sgns_init(g.n_nodes, 128, 128, 1)
+    t = time.time()
+    c_oracle.sgns_train(wk, ln, syn0, syn1, 128, 10, 5, si, cum, n_threads=12)
+    ref, _ = linkpred.get_roc_score(torch.from_numpy(syn0).cuda(), te_d, neg_d)
+    print("[%s] CPU comparator 12 threads: AUC %.5f (%.0fs)" % (kind, ref, time.time() - t), flush=True)
+    m = simulate(1, corpus, g.n_nodes, rounds, 1, "sum")
+    print("[%s] G=1: AUC %.5f" % (kind, linkpred.get_roc_score(m.vectors(), te_d, neg_d)[0]), flush=True)
+    tokens = corpus.walks.shape[0] * L
+    Gs = [int(x) for x in os.environ.get("GS", "8,2").split(",")]
+    budgets = [float(x) for x in os.environ.get("BUDGETS", "48,96,192,384").split(",")]
+    rules = os.environ.get("RULES", "hot:256,exp:0.03,exp:0.1,exp:0.3,exp:1,expa:0.1,expa:0.3").split(",")
+    delays = [int(x) for x in os.environ.get("DELAYS", "0,1").split(",")]
+    for G in Gs:
+        for budget in budgets:
+            syncs = max(1, int(np.ceil(tokens * (G - 1) / (budget * g.n_nodes))))
+            for delay in delays:
+                for rule in rules:
+                    t = time.time()
+                    extra = ""
+                    if rule.startswith("hyb:"):
+                        if delay != delays[0]:
+                            continue
+                        _, nb, theta = rule.split(":")
+                        m, frac = simulate_hybrid(G, corpus, g.n_nodes, rounds, syncs, "hot:" + nb, float(theta))
+                        extra = " hot rows %.3f/%.3f" % tuple(frac)
+                    else:
+                        m = simulate(G, corpus, g.n_nodes, rounds, syncs, rule, delay)
+                    auc, _ = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
+                    print("[%s] G=%d budget=%g syncs=%d delay=%d rule=%-12s AUC %.5f  d=%+.5f  (%.1fs)%s"
+                          % (kind, G, budget, syncs, delay, rule, auc, auc - ref, time.time() - t, extra), flush=True)
+    if th is not None:
+        th.join()
+        a, _ = linkpred.get_roc_score(torch.from_numpy(seq["syn0"]).cuda(), te_d, neg_d)
+        print("[%s] CPU comparator 1 thread: AUC %.5f (%.0fs)   [12-thread %.5f]" % (kind, a, seq["t"], ref), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -88,12 +88,12 @@ def test_dense_of_unknown_label_raises():
 
 
 def test_abi_exports_every_declared_symbol():
-    """Every function include/n2v_hip.h and include/n2v_bine.h declare is exported by the built library and
+    """Every function include/n2v_hip.h, n2v_bine.h and n2v_sim.h declare is exported by the built library and
     bound (with a signature) by the ctypes layer."""
     import __graft_entry__ as ge
     ge.build()
     from n2v_hip import _lib
-    hdr = open(os.path.join(ROOT, "include", "n2v_hip.h")).read() + open(os.path.join(ROOT, "include", "n2v_bine.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("n2v_hip.h", "n2v_bine.h", "n2v_sim.h"))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(n2v_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
