@@ -24,19 +24,6 @@ __device__ __forceinline__ void vose_inplace(n2v_alias_slot* __restrict__ T, int
     n2v::vose_pair<n2v::kProb>(T, K);
 }
 
-__device__ __forceinline__ bool row_contains(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                                             int32_t u, int32_t v) {
-    int64_t lo = row_ptr[u];
-    const int64_t end = row_ptr[u + 1];
-    int64_t hi = end;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (col[mid] < v) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo < end && col[lo] == v;
-}
-
 __global__ void __launch_bounds__(256)
 setup_tables_kernel(int64_t n_tables, const int64_t* __restrict__ tab_off, n2v_alias_slot* __restrict__ slots) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -82,7 +69,7 @@ edge_tables_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restric
         if (nb == src) u = wt / p;                               // :143-144
         // G.has_edge(dst_nbr, src), :145-146; on an undirected graph that is "dst_nbr in row(src)":
         // the lane then probes ONE row for all of its slots instead of a different row per slot
-        else if (symmetric ? row_contains(row_ptr, col, src, nb) : row_contains(row_ptr, col, nb, src)) u = wt;
+        else if (symmetric ? n2v::row_contains(row_ptr, col, src, nb) : n2v::row_contains(row_ptr, col, nb, src)) u = wt;
         else u = wt / q;                                         // :147-148
         T[k].q = u;
         norm = norm + u;  // sum(), :149

@@ -32,27 +32,6 @@ struct WalkArgs {
     int32_t* lens;
 };
 
-// Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (walk lo, walk hi, step, 0).
-__device__ __forceinline__ void philox_uniforms(uint64_t seed, uint64_t walk, uint32_t step,
-                                                double& u1, double& u2) {
-    uint32_t c0 = (uint32_t)walk, c1 = (uint32_t)(walk >> 32), c2 = step, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0;
-        c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
-        c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    // 53-bit doubles built exactly like MT19937's genrand_res53 (numpy random_sample)
-    u1 = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
-    u2 = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) / 9007199254740992.0;
-}
-
 template <int RNG, bool VEC4>
 __global__ void __launch_bounds__(256) walk_kernel(WalkArgs a) {
     const int64_t lw = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -82,7 +61,7 @@ __global__ void __launch_bounds__(256) walk_kernel(WalkArgs a) {
             u1 = u.x;
             u2 = u.y;
         } else {
-            philox_uniforms(a.seed, gw, t, u1, u2);
+            n2v::philox_uniforms(a.seed, gw, t, u1, u2);
         }
         ++t;
         const uint32_t kk = (uint32_t)(u1 * (double)K);  // int(floor(rand()*K)), :277

@@ -15,6 +15,8 @@
 // Tables are expanded from the thin, reference-exact tables, so the walks are bit-identical.
 #include "n2v_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct FatArgs {
@@ -30,20 +32,6 @@ struct FatArgs {
     int32_t* walks;
     int32_t* lens;
 };
-
-__device__ __forceinline__ void philox_uniforms(uint64_t seed, uint64_t walk, uint32_t step, double& u1, double& u2) {
-    uint32_t c0 = (uint32_t)walk, c1 = (uint32_t)(walk >> 32), c2 = step, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    u1 = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
-    u2 = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) / 9007199254740992.0;
-}
 
 template <int RNG, bool VEC4>
 __global__ void __launch_bounds__(256) walk_fat_kernel(FatArgs a) {
@@ -68,7 +56,7 @@ __global__ void __launch_bounds__(256) walk_fat_kernel(FatArgs a) {
             const double2 u = *reinterpret_cast<const double2*>(up + 2 * (int64_t)t);
             u1 = u.x; u2 = u.y;
         } else {
-            philox_uniforms(a.seed, gw, t, u1, u2);
+            n2v::philox_uniforms(a.seed, gw, t, u1, u2);
         }
         ++t;
         const uint32_t kk = (uint32_t)(u1 * (double)K);  // :277
@@ -99,6 +87,99 @@ __global__ void __launch_bounds__(256) walk_fat_kernel(FatArgs a) {
         for (int32_t i = 1; i < L; ++i) out[i] = step();
     }
     a.lens[lw] = len;
+}
+
+// Round-2 variant.  tools/lab/gather_lab*.hip: the chip serves ~4.9e10 random 16-B gathers/s from a 56 GB table but
+// only 3.8e10 32-B slots/s when a lane fetches its slot with two dwordx4 loads (each load instruction is its own
+// request to the same 64-B line), and 16-B pieces of output rows cost a partial-line write each.  So here
+//   PAIR : lanes 2i and 2i+1 fetch the two halves of ONE slot with ONE load instruction — 32 contiguous bytes per
+//          lane pair, i.e. one request per walk step — first for the even lane's walk, then for the odd lane's, and
+//          swap the halves they fetched for each other through DPP (quad_perm [1,0,3,2]);
+//   BURST: node ids leave the lane as whole 64-B lines (16 steps buffered in registers).
+// Same draws, same order of operations per walk: the walks are bit-identical to walk_fat_kernel's.
+__device__ __forceinline__ uint32_t dpp_swap1(uint32_t v) {   // value of lane ^ 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint4 dpp_swap1(uint4 v) {
+    return make_uint4(dpp_swap1(v.x), dpp_swap1(v.y), dpp_swap1(v.z), dpp_swap1(v.w));
+}
+
+template <int RNG, bool PAIR, int BURST>
+__global__ void __launch_bounds__(256) walk_fat2_kernel(FatArgs a) {
+    const int64_t lw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool mine = lw < a.n_local;          // the last pair may have one lane without a walk: it still helps its partner
+    const int32_t L = a.L;
+    int64_t rl = 0, pl = 0;
+    if (mine) { rl = lw / a.pos_count; pl = lw - rl * a.pos_count; }
+    const uint64_t gw = (uint64_t)((a.round_begin + rl) * a.n_starts + a.pos_begin + pl);
+    const int32_t cur0 = mine ? a.starts[a.pos_begin + pl] : 0;
+    int64_t b0 = 0, b1 = 0;
+    if (mine) { b0 = a.row_ptr[cur0]; b1 = a.row_ptr[cur0 + 1]; }
+    const n2v_fat_slot* tab = a.node_fat + b0;  // first step: node table (:69-70)
+    uint32_t K = (uint32_t)(b1 - b0);
+    int32_t len = 1;
+    uint32_t t = 0;
+    const double* up = nullptr;
+    if (RNG == N2V_RNG_UNIFORMS && mine) up = a.uniforms + (a.walk_uoff ? a.walk_uoff[lw] : (int64_t)2 * (L - 1) * lw);
+    const int odd = threadIdx.x & 1;
+
+    auto step = [&]() -> int32_t {
+        const bool live = mine && K != 0;       // dead end: stop, consume nothing (:76-77)
+        double u1 = 0.0, u2 = 0.0;
+        if (live) {
+            if (RNG == N2V_RNG_UNIFORMS) {
+                const double2 u = *reinterpret_cast<const double2*>(up + 2 * (int64_t)t);
+                u1 = u.x; u2 = u.y;
+            } else {
+                n2v::philox_uniforms(a.seed, gw, t, u1, u2);
+            }
+            ++t;
+        }
+        const uint32_t kk = (uint32_t)(u1 * (double)K);  // :277
+        const uint64_t addr = live ? (uint64_t)(uintptr_t)(tab + kk) : 0ull;
+        uint4 lo, hi;
+        if (PAIR) {
+            const uint64_t other = ((uint64_t)dpp_swap1((uint32_t)(addr >> 32)) << 32) | dpp_swap1((uint32_t)addr);
+            const uint64_t even_addr = odd ? other : addr, odd_addr = odd ? addr : other;
+            uint4 x = make_uint4(0, 0, 0, 0), y = x;
+            if (even_addr) x = *reinterpret_cast<const uint4*>(even_addr + (odd ? 16 : 0));   // the pair reads 32 contiguous bytes
+            if (odd_addr) y = *reinterpret_cast<const uint4*>(odd_addr + (odd ? 16 : 0));
+            const uint4 got = dpp_swap1(odd ? x : y);
+            lo = odd ? got : x;
+            hi = odd ? y : got;
+        } else {
+            lo = hi = make_uint4(0, 0, 0, 0);
+            if (live) { const uint4* p = reinterpret_cast<const uint4*>(addr); lo = p[0]; hi = p[1]; }
+        }
+        if (!live) return -1;
+        const double q = __hiloint2double((int)lo.y, (int)lo.x);
+        const bool keep = u2 < q;  // :278
+        const uint32_t slot_lo = keep ? lo.z : hi.y;
+        const uint32_t deg_hi = keep ? lo.w : hi.z;
+        const uint32_t dst = keep ? hi.x : hi.w;
+        tab = a.fat + (((uint64_t)(deg_hi >> 24) << 32) | slot_lo);
+        K = deg_hi & 0xFFFFFFu;
+        ++len;
+        return (int32_t)dst;
+    };
+
+    int32_t* out = a.walks + lw * (int64_t)L;
+    int32_t buf[BURST];
+    buf[0] = cur0;
+#pragma unroll
+    for (int i = 1; i < BURST; ++i) buf[i] = step();
+    for (int32_t g = 0;;) {
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < BURST; i += 4)
+                *reinterpret_cast<int4*>(out + g + i) = make_int4(buf[i], buf[i + 1], buf[i + 2], buf[i + 3]);
+        }
+        g += BURST;
+        if (g >= L) break;
+#pragma unroll
+        for (int i = 0; i < BURST; ++i) buf[i] = step();
+    }
+    if (mine) a.lens[lw] = len;
 }
 
 // One wavefront expands one table: fat[t+k] = {thin[t+k].q, rec(base+k), rec(base+J[k])} where
@@ -171,7 +252,24 @@ extern "C" int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat
     const bool vec4 = walk_length >= 4 && (walk_length % 4) == 0 && ((uintptr_t)walks & 15) == 0;
     const dim3 grid(n2v::grid_for(n_local, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (rng_mode == N2V_RNG_UNIFORMS) {
+    // default: pair-cooperative slot fetch + 64-B output lines whenever the row length allows it (L % 16 == 0);
+    // N2V_WALK_VARIANT = 0 (round 1's kernel) / 1 (pair, 16-B pieces) / 2 (pair, 64-B lines) / 3 (two loads, 64-B lines)
+    // is a tuning switch for tools/walk_probe.py
+    const char* env = getenv("N2V_WALK_VARIANT");
+    int variant = env ? atoi(env) : 2;
+    if ((variant == 2 || variant == 3) && !(walk_length % 16 == 0 && ((uintptr_t)walks & 63) == 0)) variant = 1;
+    if (variant == 1 && !vec4) variant = 0;
+    const bool par = rng_mode == N2V_RNG_UNIFORMS;
+    if (variant == 1) {
+        if (par) hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_UNIFORMS, true, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_PHILOX, true, 4>), grid, block, 0, st, a);
+    } else if (variant == 2) {
+        if (par) hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_UNIFORMS, true, 16>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_PHILOX, true, 16>), grid, block, 0, st, a);
+    } else if (variant == 3) {
+        if (par) hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_UNIFORMS, false, 16>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_PHILOX, false, 16>), grid, block, 0, st, a);
+    } else if (par) {
         if (vec4) hipLaunchKernelGGL((walk_fat_kernel<N2V_RNG_UNIFORMS, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((walk_fat_kernel<N2V_RNG_UNIFORMS, false>), grid, block, 0, st, a);
     } else {

@@ -43,33 +43,6 @@ struct OtfArgs {
     int32_t* status;
 };
 
-__device__ __forceinline__ void philox_uniforms(uint64_t seed, uint64_t walk, uint32_t step, double& u1, double& u2) {
-    uint32_t c0 = (uint32_t)walk, c1 = (uint32_t)(walk >> 32), c2 = step, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    u1 = ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) / 9007199254740992.0;
-    u2 = ((double)(c2 >> 5) * 67108864.0 + (double)(c3 >> 6)) / 9007199254740992.0;
-}
-
-__device__ __forceinline__ bool row_contains(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                                             int32_t u, int32_t v) {
-    int64_t lo = row_ptr[u];
-    const int64_t end = row_ptr[u + 1];
-    int64_t hi = end;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (col[mid] < v) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo < end && col[lo] == v;
-}
-
 __device__ __forceinline__ void wave_sync() {  // order this wave's LDS / scratch traffic between phases
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -108,8 +81,8 @@ __device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t
         double u;
         if (prev < 0) u = wt;
         else if (nb == prev) u = wt / a.p;
-        else if (a.symmetric ? row_contains(a.row_ptr, a.col, prev, nb)   // every lane probes prev's row
-                             : row_contains(a.row_ptr, a.col, nb, prev)) u = wt;
+        else if (a.symmetric ? n2v::row_contains(a.row_ptr, a.col, prev, nb)   // every lane probes prev's row
+                             : n2v::row_contains(a.row_ptr, a.col, nb, prev)) u = wt;
         else u = wt / a.q;
         T[k].q = u;
     }
@@ -228,7 +201,7 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
             double u1, u2;
             const uint32_t t = (uint32_t)(len - 1);
             if (a.rng_mode == N2V_RNG_UNIFORMS) { u1 = up[2 * (int64_t)t]; u2 = up[2 * (int64_t)t + 1]; }
-            else philox_uniforms(a.seed, gw, t, u1, u2);
+            else n2v::philox_uniforms(a.seed, gw, t, u1, u2);
             const int kk = (int)(u1 * (double)K);  // :277
             double qk; int Jk;
             if (K <= kLdsSlots) { qk = Tl[kk].q; Jk = Tl[kk].J; }

@@ -48,63 +48,123 @@ class WalkEngine:
     def _stream(self):
         return _lib.stream_ptr(self.device)
 
-    def preprocess(self, first_order_shortcut=True, fat="auto"):
+    def preprocess(self, first_order_shortcut=True, fat="auto", builder="wave"):
         """preprocess_transition_probs (src/node2vec.py:176-204) on device.
 
         With p == q == 1 every (src,dst) table is bit-identical to dst's node table
         (w/1 == w), so the Σdeg² edge tables are not materialised unless
-        ``first_order_shortcut=False``."""
+        ``first_order_shortcut=False``.
+
+        fat: "auto" (fat 32-B slots if they fit, else thin 16-B slots), True, False, or "both" (tests / probes:
+        thin and fat side by side).  The edge tables exist ONCE: the wave-per-table kernel writes the chosen
+        layout directly; (J, q) of a stored fat table are recovered by `thin_view` for the dict-like views.
+        builder: "wave" (n2v_build_edge_tables_wave) or "lane" (round 1's one-lane-per-table kernel, kept as a
+        cross-check of the same bits)."""
         csr, d = self.csr, self.device
         N, nnz = csr.n_nodes, csr.nnz
+        self.timings = {}
+        tick = self._phase_timer()
+        self.node_slots = self.edge_slots = self.recs = self.node_fat = self.edge_fat = None
         with torch.cuda.device(d):
             status = torch.zeros(1, dtype=torch.int32, device=d)
             self.node_slots = torch.zeros((max(nnz, 1), 2), dtype=torch.int64, device=d)
             _lib.check(self.lib.n2v_build_node_tables(
                 N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(self.node_slots),
                 _lib.ptr(status), self._stream()))
+            tick("node_tables")
             self.first_order = bool(first_order_shortcut and self.p == 1.0 and self.q == 1.0)
-            self.recs = torch.empty((max(nnz, 1), 4), dtype=torch.int32, device=d)
             if self.first_order:
                 self.edge_off = None
-                self.edge_slots = self.node_slots
                 total = nnz
             else:
                 kdst = self.deg[self.col.long()]
                 self.edge_off = torch.zeros(nnz + 1, dtype=torch.int64, device=d)
                 torch.cumsum(kdst, 0, out=self.edge_off[1:])
                 total = int(self.edge_off[-1].item())
-                free, _ = torch.cuda.mem_get_info(d)
-                need = total * SLOT_BYTES
-                if need > free - (1 << 30):
-                    raise MemoryError(
-                        "edge alias tables need %.1f GB (sum of deg^2 = %d slots), %.1f GB free"
-                        % (need / 1e9, total, free / 1e9))
-                self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
-                order = torch.argsort(kdst, descending=True).to(torch.int32)
-                src_of = torch.repeat_interleave(
-                    torch.arange(N, dtype=torch.int32, device=d), self.deg)
-                _lib.check(self.lib.n2v_build_edge_tables(
-                    N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
-                    self.p, self.q, 0 if csr.directed else 1, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz,
-                    _lib.ptr(self.edge_slots), _lib.ptr(status), self._stream()))
-                del order, src_of, kdst
+            self.total_slots = total
+            free, _ = torch.cuda.mem_get_info(d)
+            if fat == "auto":
+                fat = (nnz + (0 if self.first_order else total)) * FAT_BYTES < free - (8 << 30)
+            want_thin = fat in (False, "both")
+            want_fat = fat in (True, "both")
+            need = 0 if self.first_order else total * ((SLOT_BYTES if want_thin else 0) + (FAT_BYTES if want_fat else 0))
+            if need > free - (1 << 30):
+                raise MemoryError("edge alias tables need %.1f GB (sum of deg^2 = %d slots), %.1f GB free"
+                                  % (need / 1e9, total, free / 1e9))
+            # walk records first: they depend on the table OFFSETS only, and the fat slots embed them
+            self.recs = torch.empty((max(nnz, 1), 4), dtype=torch.int32, device=d)
             _lib.check(self.lib.n2v_build_edge_recs(
                 N, nnz, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.edge_off), 0,
                 self.max_degree, total, _lib.ptr(self.recs), self._stream()))
+            tick("offsets_recs")
+            if self.first_order:
+                self.edge_slots = self.node_slots
+            else:
+                order = torch.argsort(kdst, descending=True).to(torch.int32)
+                src_of = torch.repeat_interleave(torch.arange(N, dtype=torch.int32, device=d), self.deg)
+                sym = 0 if csr.directed else 1
+                tick("order")
+                if want_thin:
+                    self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
+                    if builder == "lane":
+                        _lib.check(self.lib.n2v_build_edge_tables(
+                            N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
+                            self.p, self.q, sym, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz,
+                            _lib.ptr(self.edge_slots), _lib.ptr(status), self._stream()))
+                    else:
+                        _lib.check(self.lib.n2v_build_edge_tables_wave(
+                            N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
+                            self.p, self.q, sym, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz, None,
+                            _lib.ptr(self.edge_slots), None, _lib.ptr(status), self._stream()))
+                    tick("edge_tables_thin")
+                if want_fat:
+                    self.edge_fat = torch.empty((max(total, 1), 4), dtype=torch.int64, device=d)
+                    tick("alloc_fat")
+                    if builder == "lane":
+                        assert want_thin, "the lane builder writes thin tables; fat ones are expanded from them"
+                        _lib.check(self.lib.n2v_build_fat_slots(
+                            nnz, _lib.ptr(self.edge_off), _lib.ptr(self.col), _lib.ptr(self.row_ptr),
+                            _lib.ptr(self.edge_slots), _lib.ptr(self.recs), _lib.ptr(self.edge_fat), self._stream()))
+                    else:
+                        _lib.check(self.lib.n2v_build_edge_tables_wave(
+                            N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
+                            self.p, self.q, sym, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz, _lib.ptr(self.recs),
+                            None, _lib.ptr(self.edge_fat), _lib.ptr(status), self._stream()))
+                    tick("edge_tables_fat")
+                del order, src_of, kdst
+            if want_fat and nnz > 0:
+                self.node_fat = torch.empty((max(nnz, 1), 4), dtype=torch.int64, device=d)
+                _lib.check(self.lib.n2v_build_fat_slots(
+                    N, _lib.ptr(self.row_ptr), None, _lib.ptr(self.row_ptr), _lib.ptr(self.node_slots),
+                    _lib.ptr(self.recs), _lib.ptr(self.node_fat), self._stream()))
+                if self.first_order:
+                    self.edge_fat = self.node_fat
             st = int(status.item())
+            tick("node_fat")
         if st & _lib.N2V_STATUS_ZERO_NORM:
-            self.node_slots = self.edge_slots = self.recs = None
+            self.node_slots = self.edge_slots = self.recs = self.node_fat = self.edge_fat = None
             raise ZeroDivisionError("float division by zero")
-        self.total_slots = total
-        self.node_fat = self.edge_fat = None
-        if fat == "auto":
-            free, _ = torch.cuda.mem_get_info(d)
-            fat = (nnz + (0 if self.first_order else total)) * FAT_BYTES < free - (8 << 30)
-        if fat and nnz > 0:
-            self.build_fat()
+
+    def _phase_timer(self):
+        """Wall time per preprocess phase into self.timings when N2V_TIMING is set (syncs the device after each
+        phase, so only for diagnosis: tools/preprocess_probe.py)."""
+        import os
+        import time
+        if not os.environ.get("N2V_TIMING"):
+            return lambda name: None
+        t = [time.perf_counter()]
+
+        def tick(name):
+            torch.cuda.synchronize(self.device)
+            now = time.perf_counter()
+            self.timings[name] = self.timings.get(name, 0.0) + now - t[0]
+            t[0] = now
+        return tick
 
     def build_fat(self):
-        """Expand the thin tables into 32-byte fat slots (one gather per walk step)."""
+        """Expand stored THIN tables into 32-byte fat slots (probes; preprocess() writes fat tables directly)."""
+        if self.edge_slots is None:
+            raise RuntimeError("no thin edge tables to expand (preprocess(fat=False) first)")
         csr, d = self.csr, self.device
         N, nnz = csr.n_nodes, csr.nnz
         with torch.cuda.device(d):
@@ -150,8 +210,41 @@ class WalkEngine:
         if self.first_order:
             return self.node_table(int(self.csr.col[e]))
         off = self.edge_off[e:e + 2].cpu().tolist()
-        s = self.edge_slots[off[0]:off[1]]
-        return (self.slots_J(s).cpu().numpy().astype(np.int64), self.slots_q(s).cpu().numpy())
+        J, q = self.thin_view(torch.arange(off[0], off[1], device=self.device), table_node=int(self.csr.col[e]))
+        return (J.cpu().numpy().astype(np.int64), q.cpu().numpy())
+
+    def all_edge_tables(self):
+        """(J int64, q float64) numpy arrays over all edge-table slots (tests / small graphs)."""
+        J, q = self.thin_view(torch.arange(self.total_slots, device=self.device))
+        return J.cpu().numpy(), q.cpu().numpy()
+
+    def thin_view(self, slot_idx, table_node=None):
+        """(J int64, q float64) of the given edge-table slots (device index tensor), whichever layout is stored.
+        From fat slots J is recovered as the position of the alias record's node in the row the table draws
+        from (rows hold distinct ids): `table_node` = that node when all slots belong to one table, else it is
+        looked up per slot."""
+        slot_idx = slot_idx.to(device=self.device, dtype=torch.int64)
+        if self.edge_slots is not None:
+            s = self.edge_slots[slot_idx]
+            return self.slots_J(s).long(), self.slots_q(s)
+        f = self.edge_fat[slot_idx]
+        q = f.view(torch.float64)[:, 0]
+        alias_dst = f.view(torch.int32)[:, 7].long()
+        if table_node is None:
+            if self.first_order:
+                node = torch.searchsorted(self.row_ptr, slot_idx, right=True) - 1
+            else:
+                node = self.col[torch.searchsorted(self.edge_off, slot_idx, right=True) - 1].long()
+        else:
+            node = torch.full_like(slot_idx, int(table_node))
+        # position of (node, alias_dst) in the CSR = global search over the keys row * N + col (ascending)
+        n = self.csr.n_nodes
+        keys = getattr(self, "_csr_keys", None)
+        if keys is None:
+            src_of = torch.repeat_interleave(torch.arange(n, device=self.device), self.deg)
+            keys = self._csr_keys = src_of * n + self.col.long()
+        e2 = torch.searchsorted(keys, node * n + alias_dst)
+        return e2 - self.row_ptr[node], q
 
     def build_one_node_table(self, dense):
         """get_alias_nodes_cur (src/node2vec.py:13-21, popwalk "none"): the table of one node, built on demand."""
@@ -216,6 +309,8 @@ class WalkEngine:
                 assert walks.shape == (n_local, L) and walks.dtype == torch.int32 and walks.is_contiguous()
             mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
             use_fat = self.edge_fat is not None if layout is None else (layout == "fat")
+            if not use_fat and self.edge_slots is None:
+                raise RuntimeError("thin tables were not built (preprocess(fat=False) or fat='both')")
             if use_fat:
                 if self.edge_fat is None:
                     raise RuntimeError("fat tables were not built")

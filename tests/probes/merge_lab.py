@@ -42,6 +42,13 @@ def rule_weights(rule, G, upd, alpha_now, r_opp, delay):
         u = (G - 1) / G * upd
         lam = torch.clamp(B / u.clamp_min(1e-30), max=1.0)
         return (lam + (1 - lam) / G).float()
+    if kind in ("expn", "expna"):
+        # the same contraction model with ONE constant: a row's error shrinks by e after n0 updates (expna: after
+        # n0 updates at the initial learning rate; the rate decays linearly over the pass)
+        n0 = float(arg)
+        h = (upd / G) / n0 * ((alpha_now / 0.025) if kind == "expna" else 1.0)
+        h = h.clamp_min(1e-9)
+        return (-torch.expm1(-G * h) / (G * -torch.expm1(-h))).float()
     if kind in ("exp", "expa"):
         # linear-contraction model: one replica's n updates contract a row's error by c = exp(-h); G sequential
         # blocks would contract it by c^G; weight on the sum = (1 - c^G) / (G (1 - c)).
@@ -77,9 +84,10 @@ def simulate_hybrid(G, corpus, n_nodes, rounds, syncs, rule, theta, mode="atomic
     xs = [[getattr(m, nm).clone() for nm in names] for m in models]
     upd = expected_updates(counts, n_global * float(L) / syncs)
     hot = [((G - 1) / G * upd[ti]) > theta for ti in range(2)]
-    wts = [rule_weights(rule, G, upd[ti], 0.0, 0.0, 0) for ti in range(2)]
     pending = None
     for c in range(syncs):
+        alpha_now = 0.025 - (0.025 - 1e-4) * (c + 0.5) / syncs
+        wts = [rule_weights(rule, G, upd[ti], alpha_now, 0.0, 0) for ti in range(2)]
         for r, m in enumerate(models):
             w, l, off = shards[r]
             b, e = sgns.shard_bounds(w.shape[0], syncs, c)
@@ -219,14 +227,14 @@ def main():
         for budget in budgets:
             syncs = max(1, int(np.ceil(tokens * (G - 1) / (budget * g.n_nodes))))
             for delay in delays:
-                for rule in rules:
+                for rule in [r for r in rules for _ in range(int(os.environ.get("REPS", "1")))]:
                     t = time.time()
                     extra = ""
                     if rule.startswith("hyb:"):
                         if delay != delays[0]:
                             continue
-                        _, nb, theta = rule.split(":")
-                        m, frac = simulate_hybrid(G, corpus, g.n_nodes, rounds, syncs, "hot:" + nb, float(theta))
+                        _, base_rule, nb, theta = rule.split(":")     # hyb:<rule>:<arg>:<theta>
+                        m, frac = simulate_hybrid(G, corpus, g.n_nodes, rounds, syncs, base_rule + ":" + nb, float(theta))
                         extra = " hot rows %.3f/%.3f" % tuple(frac)
                     else:
                         m = simulate(G, corpus, g.n_nodes, rounds, syncs, rule, delay)

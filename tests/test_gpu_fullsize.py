@@ -59,8 +59,8 @@ def _table_distribution_error(torch, eng, e_idx):
         first = torch.cumsum(K, 0) - K
         k = torch.arange(tbl.numel(), device=chunk.device) - first[tbl]
         slot = off[chunk][tbl] + k
-        qv = eng.slots_q(eng.edge_slots)[slot].clamp(max=1.0)   # `rand() < q` always holds for q >= 1
-        Jv = eng.slots_J(eng.edge_slots)[slot].long()
+        Jv, qv = eng.thin_view(slot)                             # (J, q) decoded from the stored (fat) slots
+        qv = qv.clamp(max=1.0)                                   # `rand() < q` always holds for q >= 1
         Kf = K[tbl].double()
         prob = qv.clone()
         prob.index_add_(0, first[tbl] + Jv, 1.0 - qv)
@@ -88,6 +88,9 @@ def test_c2_second_order_properties(torch_cuda):
     assert eng.total_slots == info["sum_deg2"] and eng.edge_fat is not None
     e_idx = torch.arange(0, cg.nnz, 13, device=eng.device)
     assert _table_distribution_error(torch, eng, e_idx) < 1e-12
+    assert eng.edge_slots is None            # one copy of the edge tables (fat); thin ones only on request:
+    eng.preprocess(fat="both")
+    assert _table_distribution_error(torch, eng, e_idx[::7]) < 1e-12
     a_w, a_l = eng.walk(eng.start_order, 10, 80, rng="philox", seed=11, layout="fat")
     b_w, b_l = eng.walk(eng.start_order, 10, 80, rng="philox", seed=11, layout="thin")
     assert torch.equal(a_w, b_w) and torch.equal(a_l, b_l)
@@ -141,6 +144,8 @@ def test_c3_full_size_properties(torch_cuda):
     pick = torch.from_numpy(rs.randint(0, cg.nnz, 40000)).to(eng.device)
     hubs = torch.argsort(eng.deg[eng.col.long()], descending=True)[:2000:40]
     assert _table_distribution_error(torch, eng, torch.cat([pick, hubs])) < 1e-11
+    assert eng.edge_slots is None and torch.cuda.memory_allocated() < 70e9    # fat tables only: 58.5 GB + graph
+    eng.preprocess(fat="both")               # thin tables next to them, for the layout comparison below
     a_w, a_l = eng.walk(eng.start_order, 2, 80, rng="philox", seed=3, layout="fat")
     b_w, b_l = eng.walk(eng.start_order, 2, 80, rng="philox", seed=3, layout="thin")
     assert torch.equal(a_w, b_w) and torch.equal(a_l, b_l)

@@ -78,8 +78,7 @@ def test_tables_match_reference(n2v, name):
     J0, q0 = g.alias_nodes[nodes[0]]
     assert J0.dtype == np.int64 and np.array_equal(J0, z["an_J"][ap[0]:ap[1]])
 
-    eq = eng.slots_q(eng.edge_slots).cpu().numpy()
-    eJ = eng.slots_J(eng.edge_slots).cpu().numpy()
+    eJ, eq = eng.all_edge_tables()      # decoded from the layout the engine stores (fat slots by default)
     eoff = eng.edge_off.cpu().numpy()
     ep = z["ae_ptr"]
     assert len(g.alias_edges) == len(z["ae_keys"])
@@ -190,8 +189,16 @@ def test_tables_and_walks_vs_c_oracle_20k(n2v, weighted, directed, p, q):
     if not eng.first_order:
         assert np.array_equal(eng.edge_off.cpu().numpy(), co.edge_off)
         T = int(co.edge_off[-1])
-        assert np.array_equal(eng.slots_J(eng.edge_slots).cpu().numpy()[:T], co.edgeJ)
-        assert np.array_equal(_bits(eng.slots_q(eng.edge_slots).cpu().numpy()[:T]), _bits(co.edgeq))
+        assert eng.edge_slots is None and eng.edge_fat is not None    # default: fat tables only, no thin copy
+        eJ, eq = eng.all_edge_tables()
+        assert np.array_equal(eJ[:T], co.edgeJ) and np.array_equal(_bits(eq[:T]), _bits(co.edgeq))
+        # thin output of the wave kernel and round 1's lane-per-table kernel: the same bits
+        for builder in ("wave", "lane"):
+            eng.preprocess(fat="both", builder=builder)
+            assert np.array_equal(eng.slots_J(eng.edge_slots).cpu().numpy()[:T], co.edgeJ), builder
+            assert np.array_equal(_bits(eng.slots_q(eng.edge_slots).cpu().numpy()[:T]), _bits(co.edgeq)), builder
+    else:
+        eng.preprocess(fat="both")
     L, r = 40, 2
     # throughput mode
     walks = g.simulate_walks(r, L)
@@ -459,6 +466,11 @@ def test_randomised_parity_sweep(n2v):
         assert np.array_equal(_bits(eng.slots_q(eng.node_slots).cpu().numpy()[:cg.nnz]), _bits(co.nodeq)), trial
         if not eng.first_order:
             T = int(co.edge_off[-1])
+            eJ, eq = eng.all_edge_tables()
+            assert np.array_equal(eJ[:T], co.edgeJ), trial
+            assert np.array_equal(_bits(eq[:T]), _bits(co.edgeq)), trial
+        eng.preprocess(fat="both")
+        if not eng.first_order:
             assert np.array_equal(eng.slots_J(eng.edge_slots).cpu().numpy()[:T], co.edgeJ), trial
             assert np.array_equal(_bits(eng.slots_q(eng.edge_slots).cpu().numpy()[:T]), _bits(co.edgeq)), trial
         r, L = int(rs.randint(1, 4)), int(rs.randint(1, 30))
