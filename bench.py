@@ -231,6 +231,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=10, help="walks per start vertex per step and per GPU (BASELINE: 10)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--syncs", default="auto", help="replica merges per SGNS pass when N > 1 (auto: staleness bound)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = BASELINE config C4 (the SAME rounds x N_nodes walks, start positions split "
+                         "over the ranks, src/main_link.py:261-264); weak = every rank walks rounds x N_nodes")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: wait for the cold rows' all-reduce at once instead of under the next interval (A/B)")
     ap.add_argument("--update-mode", default="auto", choices=["auto", "atomic", "agent", "plain"],
                     help="how racing wavefronts share embedding rows (DESIGN.md 4.3); auto = agent above 131072 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -273,7 +278,9 @@ def main():
     N = cg.n_nodes
     pos_begin, pos_end = sgns.shard_bounds(N, world, rank)
     pos_count = pos_end - pos_begin
-    rounds_total = args.rounds * world          # weak scaling: per-GPU walks = rounds * N at every world size
+    # strong (default, C4): the job is C3's rounds x N walks at every world size, a rank owns the start positions
+    # [r*N/G, (r+1)*N/G) of every round; weak: every rank walks rounds x N (rounds x world in total)
+    rounds_total = args.rounds * (world if args.scaling == "weak" else 1)
     n_local = pos_count * rounds_total
     n_global = N * rounds_total
     walks = torch.empty((n_local, L), dtype=torch.int32, device=dev)
@@ -292,9 +299,15 @@ def main():
     shard_offset = pos_begin * rounds_total
     syncs = (sgns.auto_syncs(n_global * L, N, world) if args.syncs == "auto" else int(args.syncs))
 
-    def sgns_step(step_no):
-        sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
-                   syncs_per_epoch=syncs)
+    merge_secs = {"merge": 0.0, "wait": 0.0, "n": 0}
+
+    def sgns_step(step_no, timed=False):
+        mg = sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
+                        syncs_per_epoch=syncs, overlap=not args.no_overlap)
+        if timed and mg is not None:
+            mergers.append(mg)
+
+    mergers = []
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     for s in range(args.warmup):
@@ -315,7 +328,7 @@ def main():
         steps_done += (lens.long() - 1).clamp_min(0).sum()
         e1b = ev()
         e1b.record()
-        sgns_step(args.warmup + s)
+        sgns_step(args.warmup + s, timed=True)
         e2.record()
         marks.append((e0, e1, e1b, e2))
     torch.cuda.synchronize()
@@ -324,6 +337,25 @@ def main():
     t_walk = sum(a.elapsed_time(b) for a, b, _, _ in marks) / 1e3
     t_sgns = sum(c.elapsed_time(d) for _, _, c, d in marks) / 1e3
 
+    for mg in mergers:                    # compute-stream seconds inside the merge phases of the timed passes
+        sec = mg.seconds()
+        merge_secs["merge"] += sec["merge"]
+        merge_secs["wait"] += sec["wait"]
+        merge_secs["n"] += mg.n_merges
+    comm_probe = None
+    if world > 1 and mergers and mergers[0].has_cold:
+        # what one all-reduce of the cold wire costs when nothing runs beside it (for overlap_fraction)
+        buf = mergers[0].cold_wire[0]
+        comm.all_reduce_sum(buf)
+        torch.cuda.synchronize()
+        c0, c1 = ev(), ev()
+        c0.record()
+        for _ in range(3):
+            comm.all_reduce_sum(buf)
+        c1.record()
+        torch.cuda.synchronize()
+        comm_probe = c0.elapsed_time(c1) / 3e3
+    del mergers
     stats = ctx.all_reduce_max(torch.tensor([t_total, t_walk, t_sgns], dtype=torch.float64, device=dev))
     sums = torch.tensor([float(steps_done.item()), float(model.pairs_trained())], dtype=torch.float64, device=dev)
     if world > 1:
@@ -390,13 +422,14 @@ def main():
         "unit": "walk-steps/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": t_total / K * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
         "dtype": "f64 alias draw / int32 ids (walk); f32 (SGNS)",
         "data": "synthetic",
-        "config": {"workload": desc, "walk_length": L, "rounds_per_gpu_per_step": args.rounds,
+        "config": {"workload": desc, "walk_length": L, "rounds_per_step": rounds_total,
                    "walks_per_step_global": n_global, "window": window, "negative": negative, "dim": args.dim,
                    "rng": "philox4x32-10 in-kernel (walk rule bit-identical to the reference under given uniforms)",
-                   "sharding": "start-vertex shards, %d 'hot'-weighted merges (RCCL all-reduce of both tables) per SGNS pass" % syncs
+                   "sharding": "start-vertex shards, %d 'hot'-weighted merges per SGNS pass (hot rows synchronously, cold "
+                               "rows' all-reduce under the next interval; RCCL, bf16 wire)" % syncs
                    if world > 1 else "single GPU", **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
                  "row_sharing": model.update_mode_name,
@@ -406,6 +439,15 @@ def main():
         "walk_reference_exact": exact,
         "sgns_shared_negatives": shared,
         "preprocess_seconds": t_pre, "alias_slots": eng.total_slots,
+        # N > 1 (rank 0's timers): seconds per step the compute stream spent in the merge phases, of which waiting
+        # for the cold rows' all-reduce; overlap_fraction = share of that all-reduce's stand-alone cost that was
+        # hidden under training
+        "merge_seconds": merge_secs["merge"] / K if world > 1 else None,
+        "merge_wait_seconds": merge_secs["wait"] / K if world > 1 else None,
+        "merges_per_step": merge_secs["n"] / K if world > 1 else None,
+        "cold_allreduce_seconds_standalone": comm_probe,
+        "overlap_fraction": (max(0.0, 1.0 - merge_secs["wait"] / max(comm_probe * merge_secs["n"], 1e-12))
+                             if comm_probe else None),
         # dominant kernel by time: sgns_kernel
         "roofline": {"kernel": "sgns_kernel", "bound": "hbm", "achieved": sgns_bytes_launch / sgns_launch_s / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",

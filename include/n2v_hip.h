@@ -242,6 +242,30 @@ int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, i
                    unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
                    void* stream);
 
+/* ---- replica merges of the multi-GPU trainer (no counterpart in the reference, whose gensim
+ * threads share one table: src/main.py:87 `workers=`) ------------------------------------------------------
+ * One process per GPU trains a replica x of a table on its shard; `base` is the copy all ranks agree on.  At
+ * the end of an interval a rank's change d = x - xs (xs = x at the interval's start) is sent; the summed
+ * changes S come back from the all-reduce (torch.distributed / RCCL, outside this library) and every rank sets
+ * base += w[r] * S.  Rows are in one of two tiers (hot_pos[r] >= 0: position in the compact hot buffers; < 0:
+ * cold).  HOT rows are merged at once: n2v_merge_snapshot packs their changes, the (small) all-reduce runs,
+ * n2v_merge_hot_apply folds the sum in and resets x = xs = base.  COLD rows are merged ONE INTERVAL LATE so
+ * that their all-reduce can run under the next interval's n2v_sgns_train: n2v_merge_snapshot folds in the sum
+ * that was sent one interval earlier (cold_sum_prev, NULL at the first interval), writes this interval's change
+ * to cold_wire and keeps the rank's own not-yet-merged change in x (x = xs = base + d).  n2v_merge_flush ends a
+ * pass: the last cold sum is folded in and x = xs = base on every row — identical tables on all ranks.
+ * wire_bf16 != 0: the wire buffers hold bfloat16 (round to nearest even), else float.  Tables are
+ * fp32[n_rows][stride]; wire buffers [n_rows][stride] (cold; hot rows' entries are written as 0) and
+ * [n_hot][stride] (hot).  w: float[n_rows] weight on the SUM of the changes (1 = sum, 1/world = mean).     */
+int n2v_merge_snapshot(float* x, float* xs, float* base, int64_t n_rows, int32_t stride, const float* w,
+                       const int32_t* hot_pos, const void* cold_sum_prev, void* cold_wire, void* hot_wire,
+                       int32_t wire_bf16, void* stream);
+int n2v_merge_hot_apply(float* x, float* xs, float* base, int32_t stride, const float* w,
+                        const int64_t* hot_rows, int64_t n_hot, const void* hot_sum, int32_t wire_bf16,
+                        void* stream);
+int n2v_merge_flush(float* x, float* xs, float* base, int64_t n_rows, int32_t stride, const float* w,
+                    const int32_t* hot_pos, const void* cold_sum_last, int32_t wire_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

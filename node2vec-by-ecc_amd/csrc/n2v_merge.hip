@@ -1,0 +1,144 @@
+// Replica merges of the multi-GPU skip-gram trainer — gfx950 (MI355X).  C-ABI and the scheme: include/n2v_hip.h
+// ("replica merges").  The reference has no counterpart (gensim's worker threads share ONE table,
+// src/main.py:87); across GPUs each rank trains a replica and the replicas' changes are summed over RCCL.
+// These kernels are the arithmetic around that all-reduce, fused into one pass over the tables per merge:
+// written as torch elementwise chains they moved ~3x the bytes (7 passes per table), and at a few hundred merges
+// per pass of a 1 GB table pair that costs as much as the training itself.  One wavefront per row, float2 (or
+// wider) per lane; pure streaming, bound by HBM bandwidth: 28 B per element for the snapshot pass.
+#include "n2v_common.h"
+
+namespace {
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even (what torch's .to(bfloat16) does)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <bool BF16> __device__ __forceinline__ float wire_load(const void* p, int64_t i) {
+    return BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+template <bool BF16> __device__ __forceinline__ void wire_store(void* p, int64_t i, float v) {
+    if (BF16) reinterpret_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+merge_snapshot_kernel(float* __restrict__ x, float* __restrict__ xs, float* __restrict__ base, int64_t n_rows, int stride,
+                      const float* __restrict__ w, const int32_t* __restrict__ hot_pos, const void* __restrict__ sum_prev,
+                      void* __restrict__ cold_wire, void* __restrict__ hot_wire) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const int hp = hot_pos ? hot_pos[r] : -1;
+    const float wr = w[r];
+    const int64_t o = r * stride;
+    for (int c = lane; c < stride; c += 64) {
+        const float d = x[o + c] - xs[o + c];
+        if (hp >= 0) {
+            wire_store<BF16>(hot_wire, (int64_t)hp * stride + c, d);
+            if (cold_wire) wire_store<BF16>(cold_wire, o + c, 0.f);
+        } else {
+            float b = base[o + c];
+            if (sum_prev) { b += wr * wire_load<BF16>(sum_prev, o + c); base[o + c] = b; }
+            wire_store<BF16>(cold_wire, o + c, d);
+            const float nx = b + d;      // the rank keeps its own not-yet-merged change
+            x[o + c] = nx;
+            xs[o + c] = nx;
+        }
+    }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+merge_hot_apply_kernel(float* __restrict__ x, float* __restrict__ xs, float* __restrict__ base, int stride,
+                       const float* __restrict__ w, const int64_t* __restrict__ hot_rows, int64_t n_hot,
+                       const void* __restrict__ hot_sum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (j >= n_hot) return;
+    const int64_t r = hot_rows[j];
+    const float wr = w[r];
+    const int64_t o = r * stride;
+    for (int c = lane; c < stride; c += 64) {
+        const float b = base[o + c] + wr * wire_load<BF16>(hot_sum, j * stride + c);
+        base[o + c] = b;
+        x[o + c] = b;
+        xs[o + c] = b;
+    }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+merge_flush_kernel(float* __restrict__ x, float* __restrict__ xs, float* __restrict__ base, int64_t n_rows, int stride,
+                   const float* __restrict__ w, const int32_t* __restrict__ hot_pos, const void* __restrict__ sum_last) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const bool cold = !hot_pos || hot_pos[r] < 0;
+    const float wr = w[r];
+    const int64_t o = r * stride;
+    for (int c = lane; c < stride; c += 64) {
+        float b = base[o + c];
+        if (cold && sum_last) { b += wr * wire_load<BF16>(sum_last, o + c); base[o + c] = b; }
+        x[o + c] = b;
+        xs[o + c] = b;
+    }
+}
+
+int rows_grid(int64_t n, unsigned* blocks) {
+    const int64_t b = (n + 3) / 4;
+    if (b > 0x7fffffff) return -1;
+    *blocks = (unsigned)b;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int n2v_merge_snapshot(float* x, float* xs, float* base, int64_t n_rows, int32_t stride, const float* w,
+                                  const int32_t* hot_pos, const void* cold_sum_prev, void* cold_wire, void* hot_wire,
+                                  int32_t wire_bf16, void* stream) {
+    if (n_rows < 0 || stride < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_snapshot: bad sizes");
+    if (n_rows == 0) return N2V_OK;
+    if (!x || !xs || !base || !w) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_snapshot: null pointer");
+    if (!cold_wire && !hot_pos) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_snapshot: cold rows need a wire buffer");
+    if (hot_pos && !hot_wire) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_snapshot: hot rows need a wire buffer");
+    unsigned blocks;
+    if (rows_grid(n_rows, &blocks)) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_snapshot: too many rows");
+    if (wire_bf16) hipLaunchKernelGGL((merge_snapshot_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, base,
+                                      n_rows, (int)stride, w, hot_pos, cold_sum_prev, cold_wire, hot_wire);
+    else hipLaunchKernelGGL((merge_snapshot_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, base, n_rows,
+                            (int)stride, w, hot_pos, cold_sum_prev, cold_wire, hot_wire);
+    return n2v::check_launch("n2v_merge_snapshot");
+}
+
+extern "C" int n2v_merge_hot_apply(float* x, float* xs, float* base, int32_t stride, const float* w,
+                                   const int64_t* hot_rows, int64_t n_hot, const void* hot_sum, int32_t wire_bf16,
+                                   void* stream) {
+    if (n_hot < 0 || stride < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_hot_apply: bad sizes");
+    if (n_hot == 0) return N2V_OK;
+    if (!x || !xs || !base || !w || !hot_rows || !hot_sum) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_hot_apply: null pointer");
+    unsigned blocks;
+    if (rows_grid(n_hot, &blocks)) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_hot_apply: too many rows");
+    if (wire_bf16) hipLaunchKernelGGL((merge_hot_apply_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, base,
+                                      (int)stride, w, hot_rows, n_hot, hot_sum);
+    else hipLaunchKernelGGL((merge_hot_apply_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, base,
+                            (int)stride, w, hot_rows, n_hot, hot_sum);
+    return n2v::check_launch("n2v_merge_hot_apply");
+}
+
+extern "C" int n2v_merge_flush(float* x, float* xs, float* base, int64_t n_rows, int32_t stride, const float* w,
+                               const int32_t* hot_pos, const void* cold_sum_last, int32_t wire_bf16, void* stream) {
+    if (n_rows < 0 || stride < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_flush: bad sizes");
+    if (n_rows == 0) return N2V_OK;
+    if (!x || !xs || !base || !w) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_flush: null pointer");
+    unsigned blocks;
+    if (rows_grid(n_rows, &blocks)) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_flush: too many rows");
+    if (wire_bf16) hipLaunchKernelGGL((merge_flush_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, base, n_rows,
+                                      (int)stride, w, hot_pos, cold_sum_last);
+    else hipLaunchKernelGGL((merge_flush_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, base, n_rows,
+                            (int)stride, w, hot_pos, cold_sum_last);
+    return n2v::check_launch("n2v_merge_flush");
+}

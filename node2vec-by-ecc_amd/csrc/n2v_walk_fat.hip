@@ -104,7 +104,7 @@ __device__ __forceinline__ uint4 dpp_swap1(uint4 v) {
     return make_uint4(dpp_swap1(v.x), dpp_swap1(v.y), dpp_swap1(v.z), dpp_swap1(v.w));
 }
 
-template <int RNG, bool PAIR, int BURST>
+template <int RNG, bool PAIR, int BURST, bool NT = false>
 __global__ void __launch_bounds__(256) walk_fat2_kernel(FatArgs a) {
     const int64_t lw = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool mine = lw < a.n_local;          // the last pair may have one lane without a walk: it still helps its partner
@@ -171,8 +171,12 @@ __global__ void __launch_bounds__(256) walk_fat2_kernel(FatArgs a) {
     for (int32_t g = 0;;) {
         if (mine) {
 #pragma unroll
-            for (int i = 0; i < BURST; i += 4)
-                *reinterpret_cast<int4*>(out + g + i) = make_int4(buf[i], buf[i + 1], buf[i + 2], buf[i + 3]);
+            for (int i = 0; i < BURST; i += 4) {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i v = {buf[i], buf[i + 1], buf[i + 2], buf[i + 3]};
+                if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4i*>(out + g + i));   // streamed: never re-read by this kernel
+                else *reinterpret_cast<v4i*>(out + g + i) = v;
+            }
         }
         g += BURST;
         if (g >= L) break;
@@ -253,11 +257,12 @@ extern "C" int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat
     const dim3 grid(n2v::grid_for(n_local, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     // default: pair-cooperative slot fetch + 64-B output lines whenever the row length allows it (L % 16 == 0);
-    // N2V_WALK_VARIANT = 0 (round 1's kernel) / 1 (pair, 16-B pieces) / 2 (pair, 64-B lines) / 3 (two loads, 64-B lines)
+    // N2V_WALK_VARIANT = 0 (round 1's kernel) / 1 (pair, 16-B pieces) / 2 (pair, 64-B lines) / 3 (two loads, 64-B lines) /
+    // 4 (pair, 64-B lines, nontemporal stores)
     // is a tuning switch for tools/walk_probe.py
     const char* env = getenv("N2V_WALK_VARIANT");
     int variant = env ? atoi(env) : 2;
-    if ((variant == 2 || variant == 3) && !(walk_length % 16 == 0 && ((uintptr_t)walks & 63) == 0)) variant = 1;
+    if ((variant == 2 || variant == 3 || variant == 4) && !(walk_length % 16 == 0 && ((uintptr_t)walks & 63) == 0)) variant = 1;
     if (variant == 1 && !vec4) variant = 0;
     const bool par = rng_mode == N2V_RNG_UNIFORMS;
     if (variant == 1) {
@@ -266,6 +271,9 @@ extern "C" int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat
     } else if (variant == 2) {
         if (par) hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_UNIFORMS, true, 16>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_PHILOX, true, 16>), grid, block, 0, st, a);
+    } else if (variant == 4) {
+        if (par) hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_UNIFORMS, true, 16, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_PHILOX, true, 16, true>), grid, block, 0, st, a);
     } else if (variant == 3) {
         if (par) hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_UNIFORMS, false, 16>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((walk_fat2_kernel<N2V_RNG_PHILOX, false, 16>), grid, block, 0, st, a);

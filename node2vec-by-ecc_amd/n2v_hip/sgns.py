@@ -145,7 +145,7 @@ class SgnsModel:
 
 class _ProcessGroupComm:
     """torch.distributed all-reduce (RCCL on GPUs, gloo in the CPU tests)."""
-    wire_dtype = None   # dtype the replicas' changes travel in (None: the tables themselves, fp32)
+    wire_dtype = None   # dtype the replicas' changes travel in (None: float32)
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -156,6 +156,12 @@ class _ProcessGroupComm:
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_async(self, t):
+        """Starts the all-reduce of `t` (in place) and returns a handle; handle.wait() orders everything issued
+        afterwards on the current stream behind its completion.  Over RCCL the collective runs on the process
+        group's own stream, i.e. under whatever the caller launches before it waits."""
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
 
 def shard_bounds(n_items, world, rank):
     """Contiguous shard [begin, end) of n_items for `rank` (as src/main_link.py:261-264 splits
@@ -165,123 +171,242 @@ def shard_bounds(n_items, world, rank):
     return b, min(b + per, n_items)
 
 
-def merge_replicas(tables, bases, comm, mode="hot", weights=None):
-    """Combine the replicas' tables in place at a sync point; `bases` holds the last merged copy.
-    mode 'hot' (default): base + w_row * (sum of every replica's change), w_row in [1/world, 1]
-                 from merge_weights(): rows that receive few updates per interval get the SUM of
-                 the changes (what one shared Hogwild table would have received), rows that every
-                 replica hammers (hubs, frequent negatives) get their MEAN — summing those
-                 overshoots by a factor `world`, averaging cold rows under-trains them by it.
-    mode 'delta': w_row = 1 (pure sum).   mode 'avg': w_row = 1/world (local SGD)."""
-    wire = getattr(comm, "wire_dtype", None)
-    for i, (t, b) in enumerate(zip(tables, bases)):
-        if wire is not None and mode in ("hot", "delta"):
-            # the replicas' CHANGES travel, as `wire` (bfloat16 over RCCL: half the bytes; AUC unchanged to 1e-4 on
-            # both probe graphs, profiles/r01/logs/replica_bf16_*.log)
-            d = (t - b).to(wire)
-            comm.all_reduce_sum(d)
-            d = d.to(t.dtype)
-            if mode == "hot":
-                d.mul_(weights[i][:, None])
-            torch.add(b, d, out=t)
-            b.copy_(t)
-            continue
-        comm.all_reduce_sum(t)
-        if mode == "avg":
-            t.div_(comm.world)
-        elif mode == "delta":
-            t.sub_(b, alpha=comm.world - 1)
-        elif mode == "hot":
-            t.sub_(b, alpha=comm.world).mul_(weights[i][:, None]).add_(b)
-        else:
-            raise ValueError("merge mode %r" % (mode,))
-        if b is not None:
-            b.copy_(t)
+# ------------------------------------------------------------------------------------------- replica merges
+# How G replicas (one per GPU, each trained on its shard of the walks) are combined.  Measured on one MI355X by
+# training G replicas interval by interval (tests/probes/merge_lab.py, replica_auc_probe.py; sequential CPU
+# comparator on the same walks; profiles/r02/logs/merge_*.log):
+#   * summing the replicas' changes ("delta") is what one shared Hogwild table would have received, but only for
+#     rows that get a handful of updates per interval: hub rows and frequent negatives run into saturation inside
+#     every replica, and the sum then overshoots by the factor G (hub graph, G=8: +0.02 ... divergence);
+#   * the mean ("avg", local SGD) under-trains every cold row by 1/G (-0.05 at G=8);
+#   * 'hot': per-row weight on the sum, w = lam + (1 - lam)/G, lam = min(1, HOT_BUDGET / u), u = expected updates
+#     of the row by the OTHER replicas per interval.  HOT_BUDGET 256 is the best of 16...4096 on both probe graphs
+#     (larger budgets pass through an unstable band before they reach the pure sum);
+#   * the cadence: STALENESS_BUDGET tokens per vocabulary row and interval from the other replicas.
+# Two tiers make the merges cheap: rows with u > HOT_THETA ("hot": every replica hammers them; contraction
+# matters, so does staleness) are merged synchronously — a message of those rows only — while the COLD rows, for
+# which the sum is exact to first order whenever it is applied, are merged ONE INTERVAL LATE: their all-reduce
+# (the bulk of the bytes) runs under the next interval's training.  The arithmetic around the collectives is
+# three fused kernels (csrc/n2v_merge.hip).
+HOT_BUDGET = 256.0
+HOT_THETA = 256.0
+STALENESS_BUDGET = 48.0
+MIN_WALKS_PER_LAUNCH = 8192  # informational: one wavefront trains one walk at a time; 5 356-walk launches still ran
+                             # at the full-pass rate (tools/sgns_grid_probe.py)
 
 
-HOT_BUDGET = 256.0  # updates per replica and interval above which a row is merged towards the mean
-HOT_EVERY = 8       # merges of the hot tier per full merge
-MIN_WALKS_PER_LAUNCH = 8192  # one wavefront trains one walk at a time; launches of 5 356 walks still run at the
-                             # full-pass rate (tools/sgns_grid_probe.py), much shorter ones have not been measured
-HOT_TIER_FACTOR = 2.0  # a row is in the hot tier when its expected updates per full interval exceed this many budgets
-
-
-def merge_weights(counts, interval_tokens_global, world, window, negative, device, budget=HOT_BUDGET, with_lam=False):
-    """Per-row merge weights (w_syn0, w_syn1neg) of mode 'hot'.  Expected updates of row v per
-    interval: syn0 (context rows) ~ pairs_per_token * T * p_v; syn1neg (targets) ~
-    pairs_per_token * T * (p_v + negative * p_neg_v), T = tokens of all replicas per interval,
-    p the unigram and p_neg the unigram^0.75 distribution.  With u = (world-1)/world * updates,
-    lambda = min(1, budget / u) and w = lambda + (1 - lambda) / world."""
+def expected_updates(counts, interval_tokens_global, window, negative, device):
+    """Expected updates per interval over ALL replicas of (syn0 rows, syn1neg rows): a syn0 row is the input of
+    ~(window + 0.5) pairs per occurrence of its word, a syn1neg row the positive target of as many plus
+    `negative` draws per pair from the unigram^0.75 distribution."""
     c = torch.as_tensor(counts, dtype=torch.float64, device=device)
     pv = c / c.sum().clamp_min(1)
     pn = c ** 0.75
     pn = pn / pn.sum().clamp_min(1e-300)
     ppt = window + 0.5
-    out, lams = [], []
-    for upd in (ppt * interval_tokens_global * pv, ppt * interval_tokens_global * (pv + negative * pn)):
+    return ppt * interval_tokens_global * pv, ppt * interval_tokens_global * (pv + negative * pn)
+
+
+def merge_weights(counts, interval_tokens_global, world, window, negative, device, budget=HOT_BUDGET, with_u=False):
+    """Per-row weights (w_syn0, w_syn1neg) on the SUM of the replicas' changes: with u = (world-1)/world * expected
+    updates per interval, lam = min(1, budget / u) and w = lam + (1 - lam) / world.  budget = inf gives the pure
+    sum, budget = 0 the mean."""
+    out, us = [], []
+    for upd in expected_updates(counts, interval_tokens_global, window, negative, device):
         u = (world - 1) / world * upd
-        lam = torch.clamp(budget / u.clamp_min(1e-30), max=1.0)
-        lams.append(lam)
+        lam = torch.clamp(budget / u.clamp_min(1e-30), max=1.0) if budget > 0 else torch.zeros_like(u)
+        us.append(u)
         out.append((lam + (1 - lam) / world).to(torch.float32))
-    return (out, lams) if with_lam else out
+    return (out, us) if with_u else out
 
 
-class TierPlan:
-    """Two-tier merge schedule of mode 'hot'.  Rows that every replica hammers (hubs, frequent negatives: expected
-    updates per full interval above HOT_TIER_FACTOR budgets) are merged `every` times per full interval — a message
-    of a few per cent of the table — so their replicas never drift far apart; all rows are merged once per full
-    interval.  Weights are those of merge_weights for the time a row actually waited.  Measured effect and when
-    it is switched on: hot_every_for() and DESIGN.md section 6."""
+class MergePlan:
+    """Weights and tiers of one run: identical on every rank (derived from the global word counts)."""
 
-    def __init__(self, counts, interval_tokens_global, world, window, negative, device, every=HOT_EVERY,
-                 factor=HOT_TIER_FACTOR, budget=HOT_BUDGET):
-        w_full, lam_full = merge_weights(counts, interval_tokens_global, world, window, negative, device, budget, True)
-        w_sub = merge_weights(counts, interval_tokens_global / max(every, 1), world, window, negative, device, budget)
-        self.every = int(every)
-        self.rows, self.w_rows, self.w_full = [], [], []
-        for wf, lf, ws in zip(w_full, lam_full, w_sub):
-            hot = lf < 1.0 / factor
+    def __init__(self, counts, interval_tokens_global, world, window, negative, device, mode="hot",
+                 budget=HOT_BUDGET, theta=HOT_THETA, cold_delay=True):
+        if mode not in ("hot", "delta", "avg"):
+            raise ValueError("merge mode %r" % (mode,))
+        b = {"hot": budget, "delta": float("inf"), "avg": 0.0}[mode]
+        self.w, us = merge_weights(counts, interval_tokens_global, world, window, negative, device, b, with_u=True)
+        self.world, self.cold_delay = world, bool(cold_delay)
+        self.hot_rows, self.hot_pos = [], []
+        for u in us:
+            hot = (u > theta) if cold_delay else torch.ones_like(u, dtype=torch.bool)
             rows = torch.nonzero(hot).flatten()
-            self.rows.append(rows)
-            self.w_rows.append(ws[rows].contiguous())
-            self.w_full.append(torch.where(hot, ws, wf))
-        if self.every <= 1 or all(r.numel() == 0 for r in self.rows):
-            self.every = 1
-            self.w_full = w_full
-
-    def sub_intervals(self, n_full):
-        return n_full * self.every
+            pos = torch.full((u.numel(),), -1, dtype=torch.int32, device=device)
+            pos[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=device)
+            self.hot_rows.append(rows.contiguous())
+            self.hot_pos.append(pos)
+        self.n_hot = [int(r.numel()) for r in self.hot_rows]
+        self.n_cold = [int(u.numel()) - h for u, h in zip(us, self.n_hot)]
 
 
-def merge_hot_rows(tables, bases, comm, plan):
-    """The hot tier's merge: same arithmetic as merge_replicas(mode='hot') on the gathered rows only."""
-    for t, b, rows, w in zip(tables, bases, plan.rows, plan.w_rows):
-        if rows.numel() == 0:
-            continue
-        wire = getattr(comm, "wire_dtype", None)
-        bb = b.index_select(0, rows)
-        if wire is not None:
-            x = (t.index_select(0, rows) - bb).to(wire)
-            comm.all_reduce_sum(x)
-            x = x.to(t.dtype).mul_(w[:, None]).add_(bb)
-        else:
-            x = t.index_select(0, rows)
-            comm.all_reduce_sum(x)
-            x.sub_(bb, alpha=comm.world).mul_(w[:, None]).add_(bb)
-        t.index_copy_(0, rows, x)
-        b.index_copy_(0, rows, x)
+class HipMergeOps:
+    """The merge arithmetic on device tensors: csrc/n2v_merge.hip.  No CPU path."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    @staticmethod
+    def _bf16(t):
+        if t.dtype == torch.bfloat16:
+            return 1
+        if t.dtype == torch.float32:
+            return 0
+        raise TypeError("wire buffers are bfloat16 or float32, not %s" % (t.dtype,))
+
+    def _check(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("n2v_hip: replica merges run on the GPU; there is no CPU fallback")
+
+    def snapshot(self, x, xs, base, w, hot_pos, sum_prev, cold_wire, hot_wire):
+        self._check(x)
+        ref = cold_wire if cold_wire is not None else hot_wire
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.n2v_merge_snapshot(
+                _lib.ptr(x), _lib.ptr(xs), _lib.ptr(base), int(x.shape[0]), int(x.shape[1]), _lib.ptr(w),
+                _lib.ptr(hot_pos), _lib.ptr(sum_prev), _lib.ptr(cold_wire), _lib.ptr(hot_wire), self._bf16(ref),
+                _lib.stream_ptr(x.device)))
+
+    def hot_apply(self, x, xs, base, w, hot_rows, hot_sum):
+        self._check(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.n2v_merge_hot_apply(
+                _lib.ptr(x), _lib.ptr(xs), _lib.ptr(base), int(x.shape[1]), _lib.ptr(w), _lib.ptr(hot_rows),
+                int(hot_rows.numel()), _lib.ptr(hot_sum), self._bf16(hot_sum), _lib.stream_ptr(x.device)))
+
+    def flush(self, x, xs, base, w, hot_pos, sum_last):
+        self._check(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.n2v_merge_flush(
+                _lib.ptr(x), _lib.ptr(xs), _lib.ptr(base), int(x.shape[0]), int(x.shape[1]), _lib.ptr(w),
+                _lib.ptr(hot_pos), _lib.ptr(sum_last), 0 if sum_last is None else self._bf16(sum_last),
+                _lib.stream_ptr(x.device)))
 
 
-# Sync cadence.  Measured on one MI355X by training G simulated replicas
-# (tests/probes/replica_auc_probe.py): on a 3000-node uniform graph (CPU comparator AUC 0.8961) the pure
-# sum ('delta') stays within 0.0005 while (G-1) * tokens per vocabulary row per interval is about
-# 12-22, is off by 0.0023 at 50 and diverges at 87.  On a 20k-node graph WITH hubs (comparator
-# 0.8672) no cadence rescues the pure sum (+0.006 at G=2, +0.020 at G=8: hub rows overshoot) nor
-# the mean (-0.014 / -0.050: cold rows under-train).  With the 'hot' interpolation the cadence can be relaxed:
-# budgets 24 / 48 / 96 give +0.0013 / +0.0016 / +0.0022 (G=2) and -0.0003 / +0.0010 / +0.0026 (G=8) on the
-# uniform graph and -0.0023 / -0.0015 / -0.0031 (G=2), -0.0060 / -0.0030 / -0.0039 (G=8) on the hub graph:
-# 48 is the largest budget inside the +-0.002 band on the uniform graph and the best one on the hub graph.
-STALENESS_BUDGET = 48.0
+class ReplicaMerger:
+    """One rank's side of the merges of `tables` (fp32 [N, stride] each, trained in place).
+
+    end_interval() = snapshot() -> all-reduce of the hot rows' changes (synchronous, small) -> finish(), which
+    starts the all-reduce of the cold rows' changes and returns; that sum is folded in by the NEXT snapshot().
+    flush() ends the run: every rank then holds the same tables.  `overlap=False` waits for the cold all-reduce
+    at once instead — same arithmetic, same results, nothing hidden (the A/B of the overlap).
+    The simulated-replica driver calls the three phases itself."""
+
+    def __init__(self, tables, plan, comm, overlap=True, ops=None):
+        self.t, self.plan, self.comm, self.overlap = list(tables), plan, comm, bool(overlap)
+        self.ops = ops if ops is not None else HipMergeOps()
+        dev = self.t[0].device
+        wire = getattr(comm, "wire_dtype", None) or torch.float32
+        self.xs = [t.clone() for t in self.t]
+        self.base = [t.clone() for t in self.t]
+        stride = int(self.t[0].shape[1])
+        assert all(int(t.shape[1]) == stride for t in self.t)
+        n_hot = sum(plan.n_hot)
+        # one buffer per collective: the tables' hot rows back to back, the tables' cold wires back to back
+        self.hot_wire = torch.zeros((n_hot, stride), dtype=wire, device=dev) if n_hot else None
+        self.hot_views, o = [], 0
+        for h in plan.n_hot:
+            self.hot_views.append(self.hot_wire[o:o + h] if h else None)
+            o += h
+        self.has_cold = sum(plan.n_cold) > 0
+        rows = [int(t.shape[0]) for t in self.t]
+        self.cold_wire = [torch.zeros((sum(rows), stride), dtype=wire, device=dev) for _ in range(2)] if self.has_cold else None
+        self.cold_views = None
+        if self.has_cold:
+            self.cold_views = []
+            for buf in self.cold_wire:
+                v, o = [], 0
+                for r in rows:
+                    v.append(buf[o:o + r])
+                    o += r
+                self.cold_views.append(v)
+        self.cur = 0
+        self.pending = None          # (handle, buffer index) of the cold all-reduce in flight
+        self.n_merges = 0
+        self._ev = []                # (kind, start event, end event) on the compute stream
+        self._timed = dev.type == "cuda"
+
+    # -- timing (bench.py: merge_seconds / overlap_fraction)
+    def _mark(self):
+        if not self._timed:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _span(self, kind, start):
+        if self._timed:
+            self._ev.append((kind, start, self._mark()))
+
+    def seconds(self):
+        """{'merge': compute-stream seconds inside the merge phases, 'wait': of which waiting for cold sums}."""
+        if self._timed:
+            torch.cuda.synchronize(self.t[0].device)
+        out = {"merge": 0.0, "wait": 0.0}
+        for kind, a, b in self._ev:
+            out[kind] += a.elapsed_time(b) / 1e3
+        out["merge"] += out["wait"]
+        return out
+
+    def _wait_pending(self):
+        if self.pending is None:
+            return None
+        handle, idx = self.pending
+        t0 = self._mark()
+        if handle is not None:
+            handle.wait()
+        self._span("wait", t0)
+        self.pending = None
+        return self.cold_views[idx]
+
+    # -- phases
+    def snapshot(self):
+        prev = self._wait_pending()
+        t0 = self._mark()
+        for i, t in enumerate(self.t):
+            self.ops.snapshot(t, self.xs[i], self.base[i], self.plan.w[i],
+                              self.plan.hot_pos[i] if self.plan.n_hot[i] else None,
+                              None if prev is None else prev[i],
+                              self.cold_views[self.cur][i] if self.has_cold else None, self.hot_views[i])
+        self._span("merge", t0)
+
+    def finish(self):
+        t0 = self._mark()
+        for i, t in enumerate(self.t):
+            if self.plan.n_hot[i]:
+                self.ops.hot_apply(t, self.xs[i], self.base[i], self.plan.w[i], self.plan.hot_rows[i], self.hot_views[i])
+        self._span("merge", t0)
+        if self.has_cold:
+            handle = self.comm.all_reduce_async(self.cold_wire[self.cur])
+            self.pending = (handle, self.cur)
+            self.cur ^= 1
+            if not self.overlap:
+                t0 = self._mark()
+                if handle is not None:
+                    handle.wait()
+                self._span("wait", t0)
+                self.pending = (None, self.pending[1])
+        self.n_merges += 1
+
+    def flush(self):
+        last = self._wait_pending()
+        t0 = self._mark()
+        for i, t in enumerate(self.t):
+            self.ops.flush(t, self.xs[i], self.base[i], self.plan.w[i],
+                           self.plan.hot_pos[i] if self.plan.n_hot[i] else None, None if last is None else last[i])
+        self._span("merge", t0)
+
+    def end_interval(self, last=False):
+        self.snapshot()
+        if self.hot_wire is not None:
+            t0 = self._mark()
+            self.comm.all_reduce_sum(self.hot_wire)
+            self._span("merge", t0)
+        self.finish()
+        if last:
+            self.flush()
 
 
 def auto_syncs(tokens_global, n_words, world):
@@ -301,120 +426,109 @@ def chunk_plan(n_local, n_chunks, exact=False):
     return [shard_bounds(n_local, n_chunks, c) for c in range(n_chunks)]
 
 
-def hot_every_for(n_local, n_chunks, hot_every="auto", world=2):
-    """Hot-tier merges per full interval.  "auto": HOT_EVERY with two replicas — where it brings the hub graph
-    inside the AUC band (0.8675 / 0.8672 against 0.8656 / 0.8648 without, comparator 0.8672) — and off beyond:
-    with eight replicas it helped at one cadence (+0.003) and hurt at another (-0.004); always
-    reduced so that a launch still covers MIN_WALKS_PER_LAUNCH walks."""
-    if hot_every != "auto":
-        return max(1, int(hot_every))
-    if world > 2:
-        return 1
-    return max(1, min(HOT_EVERY, n_local // (max(n_chunks, 1) * MIN_WALKS_PER_LAUNCH)))
+def _merge_setup(model, L, n_walks_global, world, syncs_per_epoch, merge, cold_delay):
+    """(n_chunks, MergePlan) — everything that decides how many collectives run is derived from GLOBAL quantities,
+    never from a rank's shard size."""
+    n_chunks = (auto_syncs(n_walks_global * L, model.n_words, world) if syncs_per_epoch == "auto"
+                else int(syncs_per_epoch))
+    n_chunks = max(1, min(n_chunks, max(1, n_walks_global // world)))
+    plan = MergePlan(model.counts, n_walks_global * L / n_chunks, world, model.window, model.negative, model.device,
+                     mode=merge, cold_delay=cold_delay)
+    return n_chunks, plan
 
 
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
-          merge="hot", hot_every="auto"):
-    """Train `epochs` passes over this rank's walks.  With a communicator the replicas are
-    merged `syncs_per_epoch` times per pass ("auto": auto_syncs), the last one at its end; the hot tier
-    (TierPlan) `hot_every` times per full interval."""
+          merge="hot", overlap=True, cold_delay=True, ops=None):
+    """Train `epochs` passes over this rank's walks.  With a communicator the replicas are merged
+    `syncs_per_epoch` times per pass ("auto": auto_syncs) by a ReplicaMerger; returns the merger (None on one
+    GPU) so that the caller can read its timers."""
     n_local = int(walks.shape[0])
     if n_walks_global is None:
         n_walks_global = n_local
     total = epochs * n_walks_global
     world = comm.world if comm is not None else 1
-    bases = None
-    n_chunks = 1
-    if world > 1:
-        bases = [model.syn0.clone(), model.syn1neg.clone()] if merge != "avg" else [None, None]
-        n_chunks = (auto_syncs(n_walks_global * int(walks.shape[1]), model.n_words, world)
-                    if syncs_per_epoch == "auto" else int(syncs_per_epoch))
-    # everything that decides how many collectives run must be the same on every rank: derived from the global
-    # walk count, never from this rank's shard size
-    per_rank = max(1, n_walks_global // world)
-    n_chunks = max(1, min(n_chunks, per_rank))
-    weights, tier, every = None, None, 1
-    if world > 1 and merge == "hot":
-        every = hot_every_for(per_rank, n_chunks, hot_every, world)
-        if n_chunks * every > per_rank:
-            every = 1
-        tier = TierPlan(model.counts, n_walks_global * int(walks.shape[1]) / n_chunks, world, model.window,
-                        model.negative, model.device, every=every)
-        weights, every = tier.w_full, tier.every
-    plan = chunk_plan(n_local, n_chunks * every, exact=world > 1)
+    if world == 1:
+        for ep in range(epochs):
+            model.train_pass(walks, lens, sentences_base=ep * n_walks_global, sentences_step=1,
+                             sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset)
+        return None
+    n_chunks, plan = _merge_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch, merge, cold_delay)
+    merger = ReplicaMerger([model.syn0, model.syn1neg], plan, comm, overlap=overlap, ops=ops)
+    chunks = chunk_plan(n_local, n_chunks, exact=True)
     for ep in range(epochs):
-        for i, (b, e) in enumerate(plan):
+        for i, (b, e) in enumerate(chunks):
             if e > b:
                 # all replicas advance together: `b` local sentences = b * world global ones
                 model.train_pass(walks[b:e], None if lens is None else lens[b:e],
                                  sentences_base=ep * n_walks_global + b * world, sentences_step=world,
                                  sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b)
-            if world > 1:
-                if (i + 1) % every == 0 or i + 1 == len(plan):
-                    merge_replicas([model.syn0, model.syn1neg], bases, comm, merge, weights)
-                else:
-                    merge_hot_rows([model.syn0, model.syn1neg], bases, comm, tier)
-    return model
+            merger.end_interval(last=(ep + 1 == epochs and i + 1 == len(chunks)))
+    return merger
 
 
-class _SimulatedComm:
-    """all_reduce_sum over replicas that live in ONE process (validation only: the replicas'
-    merges are executed one after another on snapshots taken before any of them is changed)."""
+class _SimGroup:
+    """The collectives of G replicas that live in ONE process (validation only).  Sums are formed in the wire
+    dtype one replica after the other, like a ring all-reduce in that dtype."""
 
-    def __init__(self, world, snapshots):
-        self.world, self._snap, self._i = world, snapshots, 0
+    def __init__(self, world, wire_dtype=None):
+        self.world, self.wire_dtype = world, wire_dtype
+        self._queue = []
 
-    def all_reduce_sum(self, t):
-        total = self._snap[self._i][0].clone()
-        for x in self._snap[self._i][1:]:
-            total += x
-        t.copy_(total)
-        self._i += 1
+    class _Comm:
+        def __init__(self, group):
+            self.group, self.world, self.wire_dtype = group, group.world, group.wire_dtype
+
+        def all_reduce_async(self, t):
+            self.group._queue.append(t)
+            if len(self.group._queue) == self.world:
+                _SimGroup.reduce(self.group._queue)
+                self.group._queue = []
+            return None
+
+        def all_reduce_sum(self, t):
+            raise RuntimeError("simulated replicas: the driver reduces the hot wires itself")
+
+    def comm(self):
+        return _SimGroup._Comm(self)
+
+    @staticmethod
+    def reduce(tensors):
+        acc = tensors[0].clone()
+        for t in tensors[1:]:
+            acc += t
+        for t in tensors:
+            t.copy_(acc)
 
 
 def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="hot", epochs=1,
-                             hot_every="auto"):
-    """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens,
-    shard_offset)` what rank r would hold.  Runs the same schedule and the same merge_replicas
-    arithmetic as `train`, interval by interval, so the multi-GPU scheme can be scored for AUC
-    on a one-GPU box."""
+                             cold_delay=True, wire_dtype=torch.bfloat16):
+    """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens, shard_offset)` what
+    rank r would hold.  Runs the schedule of `train` with one ReplicaMerger per replica — the same kernels, the
+    same two tiers, the same one-interval delay of the cold rows — so the multi-GPU scheme can be scored for AUC
+    on a one-GPU box.  Returns the number of merges per pass."""
     G = len(models)
     L = int(shards[0][0].shape[1])
-    n_chunks = (auto_syncs(n_walks_global * L, models[0].n_words, G) if syncs_per_epoch == "auto"
-                else int(syncs_per_epoch))
-    bases = [[m.syn0.clone(), m.syn1neg.clone()] if merge != "avg" else [None, None] for m in models]
-    per_rank = max(1, n_walks_global // G)
-    n_chunks = max(1, min(n_chunks, per_rank))
-    weights, tier, every = None, None, 1
-    if merge == "hot":
-        every = hot_every_for(per_rank, n_chunks, hot_every, G)
-        if n_chunks * every > per_rank:
-            every = 1
-        tier = TierPlan(models[0].counts, n_walks_global * L / n_chunks, G, models[0].window, models[0].negative,
-                        models[0].device, every=every)
-        weights, every = tier.w_full, tier.every
-    plans = [chunk_plan(int(w.shape[0]), n_chunks * every, exact=True) for w, _, _ in shards]
+    n_chunks, plan = _merge_setup(models[0], L, n_walks_global, G, syncs_per_epoch, merge, cold_delay)
+    group = _SimGroup(G, wire_dtype)
+    mergers = [ReplicaMerger([m.syn0, m.syn1neg], plan, group.comm()) for m in models]
+    plans = [chunk_plan(int(w.shape[0]), n_chunks, exact=True) for w, _, _ in shards]
     total = epochs * n_walks_global
     for ep in range(epochs):
-        for c in range(len(plans[0])):
+        for c in range(n_chunks):
             for r, m in enumerate(models):
                 w, l, off = shards[r]
-                b, e = plans[r][c] if c < len(plans[r]) else (0, 0)
+                b, e = plans[r][c]
                 if e > b:
                     m.train_pass(w[b:e], None if l is None else l[b:e], sentences_base=ep * n_walks_global + b * G,
-                                 sentences_step=G, sentences_total=total,
-                                 walk_id_base=ep * n_walks_global + off + b)
-            if (c + 1) % every == 0 or c + 1 == len(plans[0]):
-                snaps = [[m.syn0.clone() for m in models], [m.syn1neg.clone() for m in models]]
-                for r, m in enumerate(models):
-                    merge_replicas([m.syn0, m.syn1neg], bases[r], _SimulatedComm(G, snaps), merge, weights)
-            else:
-                names = [n for n, rows in zip(("syn0", "syn1neg"), tier.rows) if rows.numel()]
-                snaps = [[getattr(m, n).index_select(0, rows) for m in models]
-                         for n, rows in zip(("syn0", "syn1neg"), tier.rows) if rows.numel()]
-                assert len(names) == len(snaps)
-                for r, m in enumerate(models):
-                    merge_hot_rows([m.syn0, m.syn1neg], bases[r], _SimulatedComm(G, snaps), tier)
+                                 sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b)
+            for mg in mergers:
+                mg.snapshot()
+            if mergers[0].hot_wire is not None:
+                _SimGroup.reduce([mg.hot_wire for mg in mergers])
+            for mg in mergers:
+                mg.finish()
+    for mg in mergers:
+        mg.flush()
     return n_chunks
 
 

@@ -20,6 +20,9 @@ import replica_auc_probe as rap
 WINDOW, NEG, L = 10, 5, 80
 
 
+NEG_HEAT = [1.0]   # weight of a negative-sample update in a syn1neg row's expected update count ("hotb" rules)
+
+
 def expected_updates(counts, tokens_interval_global):
     """Expected row updates per interval over ALL replicas: (syn0 rows, syn1neg rows)."""
     c = counts.double()
@@ -27,7 +30,7 @@ def expected_updates(counts, tokens_interval_global):
     pn = c ** 0.75
     pn = pn / pn.sum()
     ppt = WINDOW + 0.5
-    return ppt * tokens_interval_global * pv, ppt * tokens_interval_global * (pv + NEG * pn)
+    return ppt * tokens_interval_global * pv, ppt * tokens_interval_global * (pv + NEG_HEAT[0] * NEG * pn)
 
 
 def rule_weights(rule, G, upd, alpha_now, r_opp, delay):
@@ -180,6 +183,9 @@ def simulate(G, corpus, n_nodes, rounds, syncs, rule, delay=0, mode="atomic", bf
                     x = getattr(m, nm)
                     if last:
                         x.copy_(base[ti])
+                    elif delay == 2:
+                        # a replica keeps its own not-yet-merged change at the weight it will be merged with
+                        torch.add(base[ti], Ds[r][ti] * wts[ti][:, None], out=x)
                     else:
                         torch.add(base[ti], Ds[r][ti], out=x)
                     xs[r][ti].copy_(x)
@@ -230,6 +236,15 @@ def main():
                 for rule in [r for r in rules for _ in range(int(os.environ.get("REPS", "1")))]:
                     t = time.time()
                     extra = ""
+                    NEG_HEAT[0] = 1.0
+                    if rule.startswith("hotb:"):          # hotb:<budget>:<beta>: negatives count beta updates each
+                        _, nb, beta = rule.split(":")
+                        NEG_HEAT[0] = float(beta)
+                        m = simulate(G, corpus, g.n_nodes, rounds, syncs, "hot:" + nb, delay)
+                        auc, _ = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
+                        print("[%s] G=%d budget=%g syncs=%d delay=%d rule=%-12s AUC %.5f  d=%+.5f  (%.1fs)"
+                              % (kind, G, budget, syncs, delay, rule, auc, auc - ref, time.time() - t), flush=True)
+                        continue
                     if rule.startswith("hyb:"):
                         if delay != delays[0]:
                             continue

@@ -35,3 +35,83 @@ def test_two_rank_main_writes_one_merged_embedding(tmp_path):
     assert np.isfinite(vec).all() and np.abs(vec).max() > 1e-3
     counts_total = 34 * 6 * 20   # every token of every rank's walks was counted once
     assert {l.split()[0] for l in lines[1:]} == {str(i) for i in range(1, 35)} and counts_total > 0
+
+
+_MERGE_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "node2vec-by-ecc_amd"))
+import torch, torch.distributed as dist
+from n2v_hip import sgns
+from n2v_hip import dist as n2v_dist
+ctx = n2v_dist.RankContext(backend="gloo")          # two ranks on the one GPU of the box: staged through host memory
+rank, comm = ctx.rank, ctx.comm
+assert ctx.world == 2 and comm.host_staged
+dev = ctx.device
+n, stride, K = 5000, 128, 6
+g = torch.Generator(device="cpu").manual_seed(5)
+base0 = torch.randn(n, stride, generator=g).to(dev)
+counts = (torch.rand(n, generator=g) ** 8 * 5000 + 1).long()        # a few hot rows, many cold ones
+plan = sgns.MergePlan(counts.numpy(), 2.0e5, 2, 10, 5, dev)
+assert 0 < plan.n_hot[0] < n and plan.n_cold[0] > 0
+incr = (torch.randn(K, 2, n, stride, generator=g) * 0.01).to(dev)
+results = []
+for overlap in (True, False):
+    t = base0.clone()
+    t2 = base0.clone() * 0.5
+    mg = sgns.ReplicaMerger([t, t2], plan, comm, overlap=overlap)     # HIP kernels, two tables like syn0 / syn1neg
+    for k in range(K):
+        t += incr[k, rank]                      # this rank's "training" of interval k (independent of the tables)
+        t2 -= incr[k, 1 - rank]
+        mg.end_interval(last=(k + 1 == K))
+    torch.cuda.synchronize()
+    want = base0 + plan.w[0][:, None] * incr.sum(dim=(0, 1))
+    assert torch.allclose(t, want, atol=1e-4), (overlap, (t - want).abs().max())
+    want2 = base0 * 0.5 - plan.w[1][:, None] * incr.sum(dim=(0, 1))
+    assert torch.allclose(t2, want2, atol=1e-4)
+    h = t.cpu(); o = h.clone(); dist.broadcast(o, src=0)
+    assert torch.equal(o, h)                    # identical tables on both ranks
+    sec = mg.seconds()
+    assert mg.n_merges == K and sec["merge"] > 0
+    results.append((t.clone(), t2.clone()))
+assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])   # overlap changes no bit
+ctx.close()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_merges_identical_with_and_without_overlap(tmp_path):
+    """The replica-merge protocol with the HIP kernels, two ranks on one GPU over gloo: same tables on both ranks,
+    and bit-identical tables whether the cold rows' all-reduce runs under the next interval or is waited for."""
+    script = tmp_path / "merge_worker.py"
+    script.write_text(_MERGE_WORKER % {"root": ROOT})
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = 29300 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert r.stdout.count("ok") == 2
+
+
+def test_bench_two_ranks_strong_scaling_reports_merge_timers(tmp_path):
+    """bench.py --gpus 2 (strong scaling = BASELINE config C4's split) rehearsed on the one GPU over gloo: the JSON
+    line carries merge_seconds and overlap_fraction."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = 29100 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2",
+           "--rounds", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["walk"]["steps_per_step_global"] == 100000 * 2 * 79        # the SAME job as N=1, split over the ranks
+    assert j["merge_seconds"] > 0 and j["merges_per_step"] >= 1
+    assert j["overlap_fraction"] is None or 0.0 <= j["overlap_fraction"] <= 1.0

@@ -63,17 +63,104 @@ def test_merge_weights_limits():
     assert (w1 <= w0 + 1e-7).all()                                                   # targets are hotter
     w0, w1 = merge_weights(counts, 10**6, world=1, window=10, negative=5, device="cpu")
     assert (w0 == 1).all() and (w1 == 1).all()
+    (s0, s1) = merge_weights(counts, 10**6, 8, 10, 5, "cpu", budget=float("inf"))      # 'delta': pure sum
+    (m0, m1) = merge_weights(counts, 10**6, 8, 10, 5, "cpu", budget=0.0)               # 'avg': mean
+    assert (s0 == 1).all() and (s1 == 1).all() and torch.allclose(m0, torch.full_like(m0, 1 / 8))
 
 
-def test_simulated_comm_equals_sum():
-    from n2v_hip.sgns import _SimulatedComm, merge_replicas
-    base = torch.arange(6, dtype=torch.float32).reshape(2, 3)
-    reps = [base + 1.0, base + 10.0, base + 100.0]
-    snaps = [[r.clone() for r in reps]]
-    for r in reps:
-        b = [base.clone()]
-        merge_replicas([r], b, _SimulatedComm(3, snaps), "delta")
-        assert torch.equal(r, base + 111.0) and torch.equal(b[0], r)
+def test_merge_plan_tiers():
+    """Rows the other replicas update more than HOT_THETA times per interval form the synchronous tier; the rest
+    is merged one interval late.  cold_delay=False puts every row in the synchronous tier."""
+    from n2v_hip import sgns
+    counts = np.full(1000, 100, dtype=np.int64)
+    counts[:5] = 200000                                   # five hubs
+    T = counts.sum() / 200.0                              # tokens per interval
+    plan = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"))
+    assert plan.hot_rows[0].tolist() == [0, 1, 2, 3, 4] and set(range(5)) <= set(plan.hot_rows[1].tolist())
+    assert plan.hot_pos[0][:5].tolist() == [0, 1, 2, 3, 4] and (plan.hot_pos[0][5:] == -1).all()
+    assert plan.n_hot[0] == 5 and plan.n_cold[0] == 995
+    (w0, w1), (u0, u1) = sgns.merge_weights(counts, T, 8, 10, 5, torch.device("cpu"), with_u=True)
+    assert torch.equal(plan.w[0], w0) and bool((u0[:5] > sgns.HOT_THETA).all()) and bool((u0[5:] <= sgns.HOT_THETA).all())
+    assert (plan.w[0][5:] == 1).all() and (plan.w[0][:5] < 0.2).all()
+    sync = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"), cold_delay=False)
+    assert sync.n_hot == [1000, 1000] and sync.n_cold == [0, 0]
+    avg = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"), mode="avg")
+    assert torch.allclose(avg.w[0], torch.full((1000,), 1 / 8))
+    with pytest.raises(ValueError):
+        sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"), mode="sparse")
+
+
+def _fake_plan(w, hot_rows, n):
+    """A MergePlan with hand-made tiers: one table, `hot_rows` synchronous."""
+    from n2v_hip import sgns
+    plan = sgns.MergePlan.__new__(sgns.MergePlan)
+    rows = torch.tensor(hot_rows, dtype=torch.int64)
+    pos = torch.full((n,), -1, dtype=torch.int32)
+    pos[rows] = torch.arange(len(hot_rows), dtype=torch.int32)
+    plan.w, plan.hot_rows, plan.hot_pos = [w], [rows], [pos]
+    plan.n_hot, plan.n_cold, plan.world, plan.cold_delay = [len(hot_rows)], [n - len(hot_rows)], 2, True
+    return plan
+
+
+def test_merger_protocol_is_linear_in_the_changes():
+    """When the replicas' changes do not depend on the tables (here: fixed increments), every schedule must end
+    with base0 + sum_k w * sum_r d_rk on every replica: two tiers, the cold rows one interval late, overlap on
+    or off, float32 or bfloat16 wire."""
+    from merge_reference import TorchMergeOps
+    from n2v_hip import sgns
+    G, n, stride, K = 3, 7, 4, 5
+    g = torch.Generator().manual_seed(1)
+    base0 = torch.randn(n, stride, generator=g)
+    w = torch.tensor([1.0, 1.0, 0.5, 0.25, 1.0, 0.75, 1.0])
+    incr = torch.randn(K, G, n, stride, generator=g) * 0.1
+    for wire in (None, torch.bfloat16):
+        for hot_rows in ([2, 3, 5], [], list(range(n))):
+            plan = _fake_plan(w, hot_rows, n)
+            group = sgns._SimGroup(G, wire)
+            tabs = [base0.clone() for _ in range(G)]
+            mergers = [sgns.ReplicaMerger([t], plan, group.comm(), ops=TorchMergeOps()) for t in tabs]
+            for k in range(K):
+                for r in range(G):
+                    tabs[r] += incr[k, r]
+                for mg in mergers:
+                    mg.snapshot()
+                if mergers[0].hot_wire is not None:
+                    sgns._SimGroup.reduce([mg.hot_wire for mg in mergers])
+                for mg in mergers:
+                    mg.finish()
+            for mg in mergers:
+                mg.flush()
+            want = base0 + w[:, None] * incr.sum(dim=(0, 1))
+            tol = 1e-5 if wire is None else 2e-2
+            for t in tabs:
+                assert torch.allclose(t, want, atol=tol), (wire, hot_rows, (t - want).abs().max())
+                assert torch.equal(t, tabs[0])
+            assert all(torch.equal(mg.base[0], tabs[0]) and torch.equal(mg.xs[0], tabs[0]) for mg in mergers)
+
+
+def test_cold_rows_keep_the_own_change_until_it_is_merged():
+    """After an interval a replica's cold rows hold base + its OWN change (the other replicas' changes arrive one
+    interval later); its hot rows are merged at once."""
+    from merge_reference import TorchMergeOps
+    from n2v_hip import sgns
+    n, stride = 4, 2
+    base0 = torch.zeros(n, stride)
+    plan = _fake_plan(torch.ones(n), [0], n)
+    group = sgns._SimGroup(2, None)
+    tabs = [base0.clone(), base0.clone()]
+    mergers = [sgns.ReplicaMerger([t], plan, group.comm(), ops=TorchMergeOps()) for t in tabs]
+    tabs[0] += 1.0
+    tabs[1] += 10.0
+    for mg in mergers:
+        mg.snapshot()
+    sgns._SimGroup.reduce([mg.hot_wire for mg in mergers])
+    for mg in mergers:
+        mg.finish()
+    assert tabs[0][0].tolist() == [11.0, 11.0] and tabs[1][0].tolist() == [11.0, 11.0]     # hot row: merged
+    assert tabs[0][1].tolist() == [1.0, 1.0] and tabs[1][1].tolist() == [10.0, 10.0]       # cold rows: own change only
+    for mg in mergers:          # an interval without training: the late sums arrive
+        mg.snapshot()
+    assert tabs[0][1].tolist() == [11.0, 11.0] and tabs[1][1].tolist() == [11.0, 11.0]
 
 
 def test_linkpred_metrics_match_sklearn():
@@ -99,43 +186,37 @@ def test_linkpred_metrics_match_sklearn():
 _GLOO_WORKER = r'''
 import os, sys
 sys.path.insert(0, os.path.join(%(root)r, "node2vec-by-ecc_amd"))
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
 import torch, torch.distributed as dist
 from n2v_hip import sgns
+from merge_reference import TorchMergeOps
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
 rank = dist.get_rank()
 comm = sgns._ProcessGroupComm()
 assert comm.world == 2
-for mode in ("avg", "delta", "hot"):
-    base0 = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+n, stride, K = 6, 4, 4
+g = torch.Generator().manual_seed(5)
+base0 = torch.randn(n, stride, generator=g)
+w = torch.tensor([1.0, 1.0, 0.5, 0.5, 1.0, 0.75])
+incr = torch.randn(K, 2, n, stride, generator=g)
+plan = sgns.MergePlan.__new__(sgns.MergePlan)
+rows = torch.tensor([2, 3])
+pos = torch.full((n,), -1, dtype=torch.int32); pos[rows] = torch.arange(2, dtype=torch.int32)
+plan.w, plan.hot_rows, plan.hot_pos, plan.n_hot, plan.n_cold, plan.world, plan.cold_delay = [w], [rows], [pos], [2], [4], 2, True
+results = []
+for overlap in (True, False):
     t = base0.clone()
-    bases = [base0.clone()]
-    t[rank] += 1.0 + rank            # each replica changes its own row ...
-    t[2] += 10.0 * (rank + 1)        # ... and both change row 2
-    w = [torch.tensor([1.0, 1.0, 0.5])]           # rows 0/1 cold (sum), row 2 hot (mean of 2 replicas)
-    sgns.merge_replicas([t], bases if mode != "avg" else [None], comm, mode, w)
-    want = base0.clone()
-    if mode == "avg":
-        want[0] += 0.5; want[1] += 1.0; want[2] += 15.0
-    elif mode == "delta":
-        want[0] += 1.0; want[1] += 2.0; want[2] += 30.0
-    else:
-        want[0] += 1.0; want[1] += 2.0; want[2] += 15.0
-    assert torch.allclose(t, want), (mode, t, want)
-    if mode != "avg":
-        assert torch.equal(bases[0], t)
-# hot tier: only the listed rows are exchanged and merged (weights per listed row), the others keep their drift
-class P: pass
-plan = P(); plan.rows = [torch.tensor([2]), torch.tensor([], dtype=torch.long)]; plan.w_rows = [torch.tensor([0.5]), torch.tensor([])]
-base0 = torch.arange(12, dtype=torch.float32).reshape(3, 4)
-t0, t1 = base0.clone(), base0.clone()
-bases = [base0.clone(), base0.clone()]
-t0[rank] += 1.0 + rank; t0[2] += 10.0 * (rank + 1); t1[1] += 7.0
-sgns.merge_hot_rows([t0, t1], bases, comm, plan)
-want = base0.clone(); want[rank] += 1.0 + rank; want[2] += 15.0
-assert torch.allclose(t0, want), (t0, want)
-assert torch.equal(bases[0][2], t0[2]) and torch.equal(bases[0][:2], base0[:2])
-w1 = base0.clone(); w1[1] += 7.0
-assert torch.equal(t1, w1) and torch.equal(bases[1], base0)
+    mg = sgns.ReplicaMerger([t], plan, comm, overlap=overlap, ops=TorchMergeOps())
+    for k in range(K):
+        t += incr[k, rank]                     # this rank's "training" of interval k
+        mg.end_interval(last=(k + 1 == K))
+    want = base0 + w[:, None] * incr.sum(dim=(0, 1))
+    assert torch.allclose(t, want, atol=1e-5), (overlap, t, want)
+    other = t.clone(); dist.broadcast(other, src=0)
+    assert torch.equal(other, t)               # identical tables on both ranks
+    assert mg.n_merges == K
+    results.append(t.clone())
+assert torch.equal(results[0], results[1])     # the same bits with the cold all-reduce overlapped or waited for
 b, e = sgns.shard_bounds(101, 2, rank)
 tot = torch.tensor([e - b]); dist.all_reduce(tot); assert int(tot) == 101
 dist.destroy_process_group()
@@ -172,59 +253,19 @@ def test_build_neg_samples_and_isolated_nodes():
     assert t2.labels[t2.col].tolist() == [2, 0, 4, 2] and np.array_equal(t2.start_order, full.start_order)
 
 
-def test_tier_plan_selects_hub_rows_and_degenerates_without_them():
-    import torch
+def test_auto_syncs_c3_shapes():
     from n2v_hip import sgns
-    counts = np.full(1000, 100, dtype=np.int64)
-    counts[:5] = 200000                                   # five hubs
-    T = counts.sum() / 20.0                               # tokens per full interval
-    plan = sgns.TierPlan(counts, T, 8, 10, 5, torch.device("cpu"))
-    assert plan.every == sgns.HOT_EVERY
-    assert plan.rows[0].tolist() == [0, 1, 2, 3, 4] and set(range(5)) <= set(plan.rows[1].tolist())
-    w_sub = sgns.merge_weights(counts, T / plan.every, 8, 10, 5, torch.device("cpu"))
-    w_full = sgns.merge_weights(counts, T, 8, 10, 5, torch.device("cpu"))
-    assert torch.equal(plan.w_rows[0], w_sub[0][:5])
-    cold = torch.ones(1000, dtype=torch.bool); cold[plan.rows[0]] = False
-    assert torch.equal(plan.w_full[0][cold], w_full[0][cold]) and torch.equal(plan.w_full[0][:5], w_sub[0][:5])
-    assert (plan.w_rows[0] >= 1 / 8 - 1e-6).all() and (plan.w_full[0] <= 1).all()
-    flat = sgns.TierPlan(np.full(1000, 100), 1000.0, 8, 10, 5, torch.device("cpu"))   # nobody is hot
-    assert flat.every == 1 and all(r.numel() == 0 for r in flat.rows)
+    # C3: 10M walks of 80 over 1M rows; 2 ranks -> 34 merges per pass, 8 ranks -> 934 at STALENESS_BUDGET 48
+    assert sgns.auto_syncs(10_000_000 * 80, 1_000_000, 2) == 17
+    assert sgns.auto_syncs(10_000_000 * 80, 1_000_000, 8) == 117
+    assert sgns.auto_syncs(80_000_000 * 80, 1_000_000, 8) == 934
 
 
-def test_hot_tier_frequency_respects_launch_size():
+def test_merger_without_gpu_has_no_fallback():
     from n2v_hip import sgns
-    # C3 shapes: 10M walks per rank; 2 ranks -> 34 full merges
-    assert sgns.auto_syncs(20_000_000 * 80, 1_000_000, 2) == 34
-    assert sgns.hot_every_for(10_000_000, 34, world=2) == sgns.HOT_EVERY
-    assert sgns.hot_every_for(10_000_000, 400, world=2) == 3
-    assert sgns.hot_every_for(10_000_000, 34, world=8) == 1          # measured not to help reliably beyond 2 replicas
-    assert sgns.hot_every_for(25_000, 117, world=2) == 1 and sgns.hot_every_for(25_000, 117, 8, world=8) == 8
-
-
-def test_merge_with_bf16_wire_format():
-    """Changes sent as bfloat16: base + w * sum_r bf16(t_r - base), for the full merge and the hot-tier merge."""
-    import torch
-    from n2v_hip import sgns
-
-    class TwoIdenticalReplicas:
-        world, wire_dtype = 2, torch.bfloat16
-
-        def all_reduce_sum(self, t):
-            assert t.dtype == torch.bfloat16
-            t.mul_(2)
-
-    comm = TwoIdenticalReplicas()
-    g = torch.Generator().manual_seed(0)
-    base = torch.randn(6, 8, generator=g)
-    t = base + 0.01 * torch.randn(6, 8, generator=g)
-    w = torch.tensor([1.0, 1.0, 0.5, 0.5, 0.75, 1.0])
-    want = base + w[:, None] * ((t - base).bfloat16() * 2).float()
-    tt, bb = t.clone(), base.clone()
-    sgns.merge_replicas([tt], [bb], comm, "hot", [w])
-    assert torch.allclose(tt, want, rtol=0, atol=1e-7) and torch.equal(bb, tt)
-    assert (tt - (base + w[:, None] * 2 * (t - base))).abs().max() < 2e-4      # bf16 rounding of the change only
-    plan = type("P", (), {})()
-    plan.rows, plan.w_rows = [torch.tensor([1, 4])], [w[[1, 4]]]
-    tt, bb = t.clone(), base.clone()
-    sgns.merge_hot_rows([tt], [bb], comm, plan)
-    assert torch.allclose(tt[[1, 4]], want[[1, 4]], atol=1e-7) and torch.equal(tt[[0, 2, 3, 5]], t[[0, 2, 3, 5]])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    plan = _fake_plan(torch.ones(3), [0], 3)
+    mg = sgns.ReplicaMerger([torch.zeros(3, 2)], plan, sgns._SimGroup(2).comm())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mg.snapshot()

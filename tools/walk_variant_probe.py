@@ -27,7 +27,7 @@ n = cg.n_nodes
 walks = torch.empty((n * rounds, L), dtype=torch.int32, device="cuda:0")
 lens = torch.empty(n * rounds, dtype=torch.int32, device="cuda:0")
 ref = None
-for variant in (0, 1, 2, 3, 2, 0):
+for variant in (0, 2, 4, 2, 4):
     os.environ["N2V_WALK_VARIANT"] = str(variant)
     best = 1e9
     for rep in range(4):
