@@ -130,7 +130,10 @@ def cpu_baselines(cg, p, q, walks_sample, lens_sample, counts, dim, budget_s=12.
         from n2v_hip import sgns as _ps  # same statistics, vectorised (checked equal in tests/)
         si, cum = _ps.vocab_tables(counts, 1e-3)
     stride = 128 if dim <= 128 else 256
-    for threads, nw in ((1, 2000), (os.cpu_count() or 1, 16000)):
+    # all cores: the threads this process may actually run on (affinity), and at least 4 jobs (gensim: <= 10 000 words
+    # = 125 walks of 80) per thread so that every thread is busy for the whole measurement
+    T_all = max(1, min(affinity, os.cpu_count() or 1, 64))
+    for threads, nw in ((1, 2000), (T_all, max(16000, T_all * 4 * 125))):
         nw = min(nw, walks_sample.shape[0])
         syn0, syn1 = c_oracle.sgns_init(cg.n_nodes, dim, stride, 1)
         t0 = time.perf_counter()
@@ -138,7 +141,8 @@ def cpu_baselines(cg, p, q, walks_sample, lens_sample, counts, dim, budget_s=12.
                                     n_threads=threads)
         dt = time.perf_counter() - t0
         extra["sgns_c_port_%s" % ("1thread" if threads == 1 else "allcores")] = {
-            "value": pairs / dt, "unit": "pair-updates/s", "cores": threads, "sample": "%d walks of the batch" % nw}
+            "value": pairs / dt, "unit": "pair-updates/s", "cores": threads,
+            "sample": "%d walks of the batch (%d jobs of <= 10 000 words, %.1f per thread)" % (nw, -(-nw // 125), -(-nw // 125) / threads)}
         del syn0, syn1
     out["cpu_baseline_extra"] = extra
     return out
@@ -408,12 +412,15 @@ def main():
     sgns_launch_s = sum(c.elapsed_time(d) for _, _, c, d in marks) / 1e3 / K
     walk_bytes_launch = float(steps_done.item()) / K * WALK_BYTES_PER_STEP
     sgns_bytes_launch = float(model.pairs_trained()) / K * SGNS_BYTES_PER_PAIR_128 * stride_scale
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get("%s_n1" % args.config) if world == 1 else None
+            if traffic:
+                traffic_source = ("profiles/traffic.json (%s): rocprofv3 PMC passes of tools/run_c3_profile.sh, NOT measured "
+                                  "by this run" % tj.get("_round", "r01"))
         except Exception:
             traffic = None
     result = {
@@ -452,19 +459,19 @@ def main():
         "roofline": {"kernel": "sgns_kernel", "bound": "hbm", "achieved": sgns_bytes_launch / sgns_launch_s / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": sgns_bytes_launch / sgns_launch_s / 1e9 / HBM_PEAK_GBS,
-                     "traffic": (traffic or {}).get("sgns_kernel"),
+                     "traffic": (traffic or {}).get("sgns_kernel"), "traffic_source": traffic_source,
                      "algorithmic_bytes_per_unit": SGNS_BYTES_PER_PAIR_128 * stride_scale, "unit_name": "pair",
                      "launch_ms": sgns_launch_s * 1e3},
         "roofline_walk": {"kernel": "walk_kernel", "bound": "hbm", "achieved": walk_bytes_launch / walk_launch_s / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": walk_bytes_launch / walk_launch_s / 1e9 / HBM_PEAK_GBS,
-                          "traffic": (traffic or {}).get("walk_kernel"),
+                          "traffic": (traffic or {}).get("walk_kernel"), "traffic_source": traffic_source,
                           "algorithmic_bytes_per_unit": WALK_BYTES_PER_STEP, "unit_name": "walk step",
                           "launch_ms": walk_launch_s * 1e3},
     }
     if not args.no_cpu_baseline:
         t0 = time.perf_counter()
-        ns = min(16000, n_local)
+        ns = min(32000, n_local)
         result.update(cpu_baselines(cg, p, q, walks[:ns].cpu().numpy(), lens[:ns].cpu().numpy(),
                                     model.counts, args.dim))
         log("[bench] cpu baselines took %.1fs" % (time.perf_counter() - t0))

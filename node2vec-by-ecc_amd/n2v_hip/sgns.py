@@ -189,7 +189,7 @@ def shard_bounds(n_items, world, rank):
 # (the bulk of the bytes) runs under the next interval's training.  The arithmetic around the collectives is
 # three fused kernels (csrc/n2v_merge.hip).
 HOT_BUDGET = 256.0
-HOT_THETA = 256.0
+HOT_THETA = 64.0
 STALENESS_BUDGET = 48.0
 MIN_WALKS_PER_LAUNCH = 8192  # informational: one wavefront trains one walk at a time; 5 356-walk launches still ran
                              # at the full-pass rate (tools/sgns_grid_probe.py)
@@ -288,14 +288,18 @@ class HipMergeOps:
 class ReplicaMerger:
     """One rank's side of the merges of `tables` (fp32 [N, stride] each, trained in place).
 
-    end_interval() = snapshot() -> all-reduce of the hot rows' changes (synchronous, small) -> finish(), which
-    starts the all-reduce of the cold rows' changes and returns; that sum is folded in by the NEXT snapshot().
-    flush() ends the run: every rank then holds the same tables.  `overlap=False` waits for the cold all-reduce
-    at once instead — same arithmetic, same results, nothing hidden (the A/B of the overlap).
+    end_interval() = snapshot() -> all-reduce of the hot rows' changes -> finish(), pipelined over row ranges so
+    that packing and folding run under the wire time; finish() also starts the all-reduce of the cold rows'
+    changes and returns — that sum is folded in by the NEXT snapshot().  flush() ends the run: every rank then
+    holds the same tables.  `overlap=False`: one range, and the cold all-reduce is waited for at once — same
+    arithmetic, same results, nothing hidden (the A/B of the overlap).
     The simulated-replica driver calls the three phases itself."""
 
-    def __init__(self, tables, plan, comm, overlap=True, ops=None):
+    def __init__(self, tables, plan, comm, overlap=True, ops=None, pipe=8, pipe_bytes=32 << 20):
         self.t, self.plan, self.comm, self.overlap = list(tables), plan, comm, bool(overlap)
+        self.pipe = int(pipe) if overlap else 1
+        self.pipe_bytes = int(pipe_bytes)       # a row range of the pipelined merge is at least this large
+        self._bounds = [None] * len(self.t)
         self.ops = ops if ops is not None else HipMergeOps()
         dev = self.t[0].device
         wire = getattr(comm, "wire_dtype", None) or torch.float32
@@ -378,6 +382,10 @@ class ReplicaMerger:
             if self.plan.n_hot[i]:
                 self.ops.hot_apply(t, self.xs[i], self.base[i], self.plan.w[i], self.plan.hot_rows[i], self.hot_views[i])
         self._span("merge", t0)
+        self._launch_cold()
+        self.n_merges += 1
+
+    def _launch_cold(self):
         if self.has_cold:
             handle = self.comm.all_reduce_async(self.cold_wire[self.cur])
             self.pending = (handle, self.cur)
@@ -388,7 +396,6 @@ class ReplicaMerger:
                     handle.wait()
                 self._span("wait", t0)
                 self.pending = (None, self.pending[1])
-        self.n_merges += 1
 
     def flush(self):
         last = self._wait_pending()
@@ -398,13 +405,45 @@ class ReplicaMerger:
                            self.plan.hot_pos[i] if self.plan.n_hot[i] else None, None if last is None else last[i])
         self._span("merge", t0)
 
+    def _pipe_bounds(self, i):
+        """Row ranges [a, b) of table i and the hot-wire positions [pa, pb) they own (hot rows ascend, so a row
+        range owns a contiguous piece of the hot wire): the units of the pipelined synchronous merge."""
+        if self._bounds[i] is None:
+            n = int(self.t[i].shape[0])
+            k = max(1, min(self.pipe, n * int(self.t[i].shape[1]) * 4 // self.pipe_bytes))
+            rows = [shard_bounds(n, k, c) for c in range(k)]
+            cuts = torch.tensor([a for a, _ in rows] + [n], dtype=torch.int64, device=self.plan.hot_rows[i].device)
+            pos = torch.searchsorted(self.plan.hot_rows[i], cuts).tolist() if self.plan.n_hot[i] else [0] * (k + 1)
+            self._bounds[i] = [(a, b, pos[c], pos[c + 1]) for c, (a, b) in enumerate(rows)]
+        return self._bounds[i]
+
     def end_interval(self, last=False):
-        self.snapshot()
-        if self.hot_wire is not None:
+        """snapshot -> all-reduce of the hot rows' changes -> fold in, PIPELINED over row ranges: while range c's
+        changes travel, range c+1 is being packed and range c-1 folded in, so the merge kernels run under the wire
+        time (the results are those of snapshot() / finish(), bit for bit: same kernels on the same rows)."""
+        prev = self._wait_pending()
+        inflight = []
+        for i, t in enumerate(self.t):
+            hp = self.plan.hot_pos[i] if self.plan.n_hot[i] else None
+            for (a, b, pa, pb) in self._pipe_bounds(i):
+                t0 = self._mark()
+                self.ops.snapshot(t[a:b], self.xs[i][a:b], self.base[i][a:b], self.plan.w[i][a:b],
+                                  None if hp is None else hp[a:b], None if prev is None else prev[i][a:b],
+                                  self.cold_views[self.cur][i][a:b] if self.has_cold else None, self.hot_views[i])
+                self._span("merge", t0)
+                if pb > pa:
+                    inflight.append((i, pa, pb, self.comm.all_reduce_async(self.hot_views[i][pa:pb])))
+        for (i, pa, pb, handle) in inflight:
             t0 = self._mark()
-            self.comm.all_reduce_sum(self.hot_wire)
+            if handle is not None:
+                handle.wait()
+            self._span("wait", t0)
+            t0 = self._mark()
+            self.ops.hot_apply(self.t[i], self.xs[i], self.base[i], self.plan.w[i], self.plan.hot_rows[i][pa:pb],
+                               self.hot_views[i][pa:pb])
             self._span("merge", t0)
-        self.finish()
+        self._launch_cold()
+        self.n_merges += 1
         if last:
             self.flush()
 

@@ -361,7 +361,13 @@ class Graph():
             walks, lens = eng.walk(eng.start_order, num_walks, L, rng="philox", seed=self.seed, pos_begin=b, pos_count=cnt)
             return WalkCorpus(walks, lens, self._csr.labels)
         if bool(self._csr.directed) and bool((eng.deg == 0).any().item()):
-            raise NotImplementedError("numpy-stream sharding needs walks of known length (no reachable sinks)")
+            # reachable sinks: a walk's place in the stream depends on the lengths of ALL earlier walks, whoever
+            # owns them, so every rank resolves the whole chain (same work as the single-process call) and keeps
+            # its block of rows — the union over ranks is the single-process result and the global state ends
+            # where that call leaves it
+            full = self.simulate_walks(num_walks, L)
+            rows = (torch.arange(num_walks, device=d)[:, None] * n + torch.arange(b, b + cnt, device=d)[None, :]).reshape(-1)
+            return WalkCorpus(full.walks[rows].contiguous(), full.lens[rows].contiguous(), self._csr.labels)
         active = (eng.deg[eng.start_order.long()] > 0).to(torch.int64) * (2 * (L - 1))
         prefix = torch.cumsum(active, 0) - active           # uniforms owned by earlier starts of a round
         per_round = int(active.sum().item())
@@ -389,6 +395,45 @@ class Graph():
         if getattr(self, "host_rng", False):
             return torch.from_numpy(np.random.random_sample(n)).to(device)
         return _mt.global_uniforms_device(n, device)
+
+    def _resolve_stream_offsets(self, starts, n, num_walks, L, U, active):
+        """Directed graph with reachable sinks: a walk that ends early consumes fewer uniforms, so the position
+        of walk w in numpy's stream depends on the lengths of all walks before it (src/node2vec.py:76-77 stops
+        without drawing).  The chain is resolved on the device window by window: the window's first walk has an
+        exact offset; the others are walked with offsets guessed from their last known lengths; after the scan
+        of the new lengths every walk before the first one whose offset turned out different is final, and the
+        next window starts there.  A pass costs one launch over at most 2^18 walks and one scalar read-back;
+        a pass finalises 1 / P(a re-walked walk changes its length) walks on average (round 1 re-walked ALL
+        walks per pass)."""
+        eng = self._engine
+        d = eng.device
+        W = n * num_walks
+        walks = torch.empty((W, L), dtype=torch.int32, device=d)
+        lens = torch.empty(W, dtype=torch.int32, device=d)
+        step = 2 * (L - 1)
+        guess = (active.to(torch.int64) * step).repeat(num_walks)      # uniforms each walk is assumed to consume
+        starts_all = starts.repeat(num_walks)
+        done, exact_off, window = 0, 0, 4096
+        self.stream_passes = 0
+        while done < W:
+            hi = min(W, done + window)
+            g = guess[done:hi]
+            off = (torch.cumsum(g, 0) - g + exact_off).contiguous()
+            w_win, l_win = self._walk(starts_all[done:hi].contiguous(), 1, L, rng="uniforms", uniforms=U, walk_uoff=off)
+            used = (l_win.to(torch.int64) - 1) * 2
+            new_off = torch.cumsum(used, 0) - used + exact_off
+            bad = new_off != off
+            m = hi - done
+            first = int(torch.nonzero(bad)[0].item()) if bool(bad.any().item()) else m
+            # walks [0, first) were walked from their true offsets: final
+            walks[done:done + first] = w_win[:first]
+            lens[done:done + first] = l_win[:first]
+            exact_off = int((new_off[first - 1] + used[first - 1]).item())
+            guess[done + first:hi] = used[first:]           # best guess for the re-walk: the length just seen
+            done += first
+            self.stream_passes += 1
+            window = max(1024, min(1 << 18, 4 * first if first < m else 2 * window))
+        return walks, lens
 
     def _simulate_numpy_stream(self, starts, n, num_walks, L):
         """Parity mode.  Walk w = it*n + pos owns the uniforms the sequential reference
@@ -427,16 +472,7 @@ class Graph():
             return walks, lens
         state = np.random.get_state()
         U = self._global_uniforms(total_full, d)
-        walks, lens = self._walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
-        # offsets depend on the lengths of all earlier walks: iterate to the fixed point
-        # (each pass makes at least the first not-yet-final walk final)
-        for _ in range(W + 1):
-            new_off = torch.cumsum((lens.to(torch.int64) - 1) * 2, 0)
-            new_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=d), new_off[:-1]]).contiguous()
-            if torch.equal(new_off, uoff):
-                break
-            uoff = new_off
-            walks, lens = self._walk(starts, num_walks, L, rng="uniforms", uniforms=U, walk_uoff=uoff)
+        walks, lens = self._resolve_stream_offsets(starts, n, num_walks, L, U, active)
         used = int(((lens.to(torch.int64) - 1) * 2).sum().item())
         np.random.set_state(state)
         _mt.advance_global_state(used)  # leave the global stream where the reference would

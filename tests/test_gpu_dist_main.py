@@ -58,7 +58,7 @@ results = []
 for overlap in (True, False):
     t = base0.clone()
     t2 = base0.clone() * 0.5
-    mg = sgns.ReplicaMerger([t, t2], plan, comm, overlap=overlap)     # HIP kernels, two tables like syn0 / syn1neg
+    mg = sgns.ReplicaMerger([t, t2], plan, comm, overlap=overlap, pipe_bytes=1 << 18)   # HIP kernels, two tables, 8 row ranges
     for k in range(K):
         t += incr[k, rank]                      # this rank's "training" of interval k (independent of the tables)
         t2 -= incr[k, 1 - rank]

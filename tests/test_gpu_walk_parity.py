@@ -437,6 +437,61 @@ def test_shards_reproduce_the_single_process_walks(n2v):
     assert g.simulate_walks_shard(r, L, 0, 1) == golden_walks(z, 0)
 
 
+def test_directed_sinks_sharded_and_pass_bound(n2v):
+    """Directed graphs with reachable sinks in the reference-exact mode (SURVEY.md 8(a) row 6'): (1) the golden
+    walks of er600_directed through simulate_walks_shard for 3- and 8-rank layouts (round 1 raised
+    NotImplementedError there); (2) a 5 000-node graph where a fifth of the nodes are sinks (> 10 % of the walks
+    end early): walks equal the C oracle's sequential result and the device-side offset resolution needs far
+    fewer passes than walks (round 1: up to one pass over ALL walks per early-ending walk)."""
+    import torch
+    from n2v_hip import csr
+    from oracle import c_oracle
+    z = load_case("er600_directed")
+    g = n2v.Graph(_nx_graph(z), True, float(z["p"]), float(z["q"]))
+    g.preprocess_transition_probs()
+    seed, r, L = z["walk_meta"][0][:3].tolist()
+    want = golden_walks(z, 0)
+    n = len(z["nodes"])
+    np.random.seed(seed)
+    assert g.simulate_walks(r, L) == want
+    st_full = np.random.get_state()
+    for world in (3, 8):
+        got = [None] * (r * n)
+        for rank in range(world):
+            np.random.seed(seed)
+            sh = g.simulate_walks_shard(r, L, rank, world).tolist()
+            st = np.random.get_state()
+            assert st[2] == st_full[2] and np.array_equal(st[1], st_full[1])
+            per = -(-n // world)
+            b, e = min(rank * per, n), min(rank * per + per, n)
+            for it in range(r):
+                got[it * n + b:it * n + e] = sh[it * (e - b):(it + 1) * (e - b)]
+        assert got == want, world
+    # many sinks
+    rs = np.random.RandomState(8)
+    N, M = 5000, 40000
+    src, dst = rs.randint(0, N, M), rs.randint(0, N, M)
+    keep = (src % 5 != 0) & (src != dst)                   # nodes divisible by 5 have no out-edges
+    cg = csr.from_edges(src[keep], dst[keep], None, True)
+    g2 = n2v.Graph.from_csr(cg, 0.5, 2.0, rng="numpy")
+    g2.preprocess_transition_probs()
+    co = c_oracle.CsrOracle(cg.row_ptr, cg.col, None, 0.5, 2.0)
+    co.preprocess()
+    r, L = 3, 30
+    ow, ol, nd = co.walk(cg.start_order, r, L, mode="mt", seed=77)
+    np.random.seed(77)
+    got = g2.simulate_walks(r, L)
+    assert np.array_equal(got.lens.cpu().numpy(), ol) and np.array_equal(got.walks.cpu().numpy(), ow)
+    chk = np.random.RandomState(77)
+    chk.random_sample(nd)
+    assert np.random.random_sample() == chk.random_sample()
+    W = r * cg.n_nodes
+    early = float((ol < L).mean())
+    assert early > 0.10, early
+    print("directed sinks: %d walks, %.0f%% end early, %d passes" % (W, 100 * early, g2.stream_passes))
+    assert g2.stream_passes < 0.5 * W, (g2.stream_passes, W)
+
+
 def test_randomised_parity_sweep(n2v):
     """40 random small graphs (directed or not, weighted or not, self-loops, isolated targets,
     duplicate lines, p and q from a grid incl. 1): tables and reference-exact walks vs the C oracle

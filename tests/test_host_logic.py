@@ -133,3 +133,61 @@ def test_tools_never_import_oracle():
         if f.endswith(".py"):
             txt = open(os.path.join(ROOT, "tools", f)).read()
             assert "oracle" not in txt, f
+
+
+def test_main_binds_the_rank_to_its_device_before_allocating(monkeypatch, tmp_path):
+    """One process per GPU: main() must create the RankContext (which calls set_device(LOCAL_RANK)) BEFORE the graph
+    and tables are allocated and hand that device to node2vec.Graph — otherwise every rank's tables land on cuda:0."""
+    import torch
+    import main as n2v_main
+    import node2vec
+    from n2v_hip import dist as n2v_dist
+    events = []
+
+    class FakeCtx:
+        world, rank, device = 2, 1, torch.device("cuda:1")
+
+        def __init__(self):
+            events.append("ctx")
+
+        def barrier(self):
+            pass
+
+    class FakeEngine:
+        device = torch.device("cuda:1")
+
+    class FakeGraph:
+        def __init__(self, nx_G, directed, p, q, rng=None, seed=None, device=None):
+            events.append(("graph", device))
+            self._engine, self._csr = FakeEngine(), type("C", (), {"n_nodes": 3})()
+
+        def preprocess_transition_probs(self):
+            events.append("preprocess")
+
+        def simulate_walks_shard(self, r, L, rank, world):
+            events.append(("walk", rank, world))
+            return "walks"
+
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(n2v_dist, "RankContext", FakeCtx)
+    monkeypatch.setattr(node2vec, "Graph", FakeGraph)
+    monkeypatch.setattr(n2v_main, "read_graph", lambda: "nx")
+    monkeypatch.setattr(n2v_main, "learn_embeddings", lambda walks, **kw: ("emb", kw["ctx"].device))
+    args = n2v_main.parse_args(["--input", "x", "--rng", "philox"])
+    out = n2v_main.main(args)
+    assert events[0] == "ctx" and events[1] == ("graph", torch.device("cuda:1")) and events[2] == "preprocess"
+    assert events[3] == ("walk", 1, 2) and out == ("emb", torch.device("cuda:1"))
+
+
+def test_save_embeddings_creates_the_output_directory(tmp_path):
+    import main as n2v_main
+
+    class Emb:
+        class wv:
+            @staticmethod
+            def save_word2vec_format(path):
+                open(path, "w").write("0 0\n")
+    target = tmp_path / "emb" / "deep" / "karate.emb"
+    n2v_main.save_embeddings(Emb, str(target))
+    assert target.read_text() == "0 0\n"

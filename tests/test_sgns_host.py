@@ -206,7 +206,7 @@ plan.w, plan.hot_rows, plan.hot_pos, plan.n_hot, plan.n_cold, plan.world, plan.c
 results = []
 for overlap in (True, False):
     t = base0.clone()
-    mg = sgns.ReplicaMerger([t], plan, comm, overlap=overlap, ops=TorchMergeOps())
+    mg = sgns.ReplicaMerger([t], plan, comm, overlap=overlap, ops=TorchMergeOps(), pipe=3, pipe_bytes=32)
     for k in range(K):
         t += incr[k, rank]                     # this rank's "training" of interval k
         mg.end_interval(last=(k + 1 == K))
