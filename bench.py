@@ -309,6 +309,8 @@ def main():
         mg = sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
                         syncs_per_epoch=syncs, overlap=not args.no_overlap)
         if timed and mg is not None:
+            if mergers:
+                mergers[-1].release()       # keep the timers, not 2.5 GB of snapshots per timed step
             mergers.append(mg)
 
     mergers = []
@@ -347,9 +349,11 @@ def main():
         merge_secs["wait"] += sec["wait"]
         merge_secs["n"] += mg.n_merges
     comm_probe = None
-    if world > 1 and mergers and mergers[0].has_cold:
-        # what one all-reduce of the cold wire costs when nothing runs beside it (for overlap_fraction)
-        buf = mergers[0].cold_wire[0]
+    if world > 1 and mergers:
+        # what one merge's all-reduce costs when nothing runs beside it (for overlap_fraction): the wire buffer that
+        # carries the bulk of the rows — the synchronous tier's unless most rows are in the delayed tier
+        mg0 = mergers[-1]
+        buf = mg0.hot_wire if (mg0.hot_wire is not None and (not mg0.has_cold or sum(mg0.plan.n_hot) >= sum(mg0.plan.n_cold))) else mg0.cold_wire[0]
         comm.all_reduce_sum(buf)
         torch.cuda.synchronize()
         c0, c1 = ev(), ev()
@@ -452,7 +456,7 @@ def main():
         "merge_seconds": merge_secs["merge"] / K if world > 1 else None,
         "merge_wait_seconds": merge_secs["wait"] / K if world > 1 else None,
         "merges_per_step": merge_secs["n"] / K if world > 1 else None,
-        "cold_allreduce_seconds_standalone": comm_probe,
+        "allreduce_seconds_standalone": comm_probe,
         "overlap_fraction": (max(0.0, 1.0 - merge_secs["wait"] / max(comm_probe * merge_secs["n"], 1e-12))
                              if comm_probe else None),
         # dominant kernel by time: sgns_kernel

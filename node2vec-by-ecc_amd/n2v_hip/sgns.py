@@ -173,22 +173,34 @@ def shard_bounds(n_items, world, rank):
 
 # ------------------------------------------------------------------------------------------- replica merges
 # How G replicas (one per GPU, each trained on its shard of the walks) are combined.  Measured on one MI355X by
-# training G replicas interval by interval (tests/probes/merge_lab.py, replica_auc_probe.py; sequential CPU
-# comparator on the same walks; profiles/r02/logs/merge_*.log):
+# training G replicas interval by interval (tests/probes/merge_lab.py; sequential single-thread CPU comparator on the
+# same walks; 3 000-node uniform graph, comparator AUC 0.89607, and 20 000-node hub graph, max degree 597, comparator
+# 0.86678; logs under profiles/r02/logs/merge_lab*.log; a configuration reproduces to 1e-4 from run to run):
 #   * summing the replicas' changes ("delta") is what one shared Hogwild table would have received, but only for
 #     rows that get a handful of updates per interval: hub rows and frequent negatives run into saturation inside
-#     every replica, and the sum then overshoots by the factor G (hub graph, G=8: +0.02 ... divergence);
-#   * the mean ("avg", local SGD) under-trains every cold row by 1/G (-0.05 at G=8);
+#     every replica and the sum then overshoots by the factor G (hub graph, 8 replicas: +0.03 at 234 merges per
+#     pass, divergence at 59);
+#   * the mean ("avg", local SGD) under-trains every cold row by 1/G (-0.05 at 8 replicas);
 #   * 'hot': per-row weight on the sum, w = lam + (1 - lam)/G, lam = min(1, HOT_BUDGET / u), u = expected updates
-#     of the row by the OTHER replicas per interval.  HOT_BUDGET 256 is the best of 16...4096 on both probe graphs
-#     (larger budgets pass through an unstable band before they reach the pure sum);
-#   * the cadence: STALENESS_BUDGET tokens per vocabulary row and interval from the other replicas.
-# Two tiers make the merges cheap: rows with u > HOT_THETA ("hot": every replica hammers them; contraction
-# matters, so does staleness) are merged synchronously — a message of those rows only — while the COLD rows, for
-# which the sum is exact to first order whenever it is applied, are merged ONE INTERVAL LATE: their all-reduce
-# (the bulk of the bytes) runs under the next interval's training.  The arithmetic around the collectives is
-# three fused kernels (csrc/n2v_merge.hip).
-HOT_BUDGET = 256.0
+#     of the row by the OTHER replicas per interval.  AUC minus comparator at STALENESS_BUDGET 48 for HOT_BUDGET
+#     160 / 192 / 224 / 256 / 320: hub graph, 8 replicas -0.0011 / -0.0011 / -0.0017 / -0.0027 / -0.0068, uniform
+#     graph +0.0021 / +0.0018 / +0.0014 / +0.0010 / +0.0002 (two replicas: -0.0015 and +0.0018 whatever the budget);
+#     budgets of 512 and more pass through an unstable band (-0.014 ... +0.02) before they reach the pure sum.
+#     208 keeps all four cases inside +-0.002, with margins of 0.0003-0.0006 — the scheme has no slack left;
+#   * the cadence: STALENESS_BUDGET tokens per vocabulary row and interval from the other replicas.  24 / 32 / 48 /
+#     64 / 96 at 8 replicas (HOT_BUDGET 256): hub -0.0055 / -0.0047 / -0.0027 / -0.0023 / -0.0035, uniform -0.0003 /
+#     -0.0001 / +0.0010 / +0.0020 / -0.0004;
+#   * smooth "contraction model" weights w = (1 - exp(-G h)) / (G (1 - exp(-h))) with h ~ updates / n0 (optionally
+#     scaled by the decaying learning rate) were no better and less stable (merge_lab3.log);
+#   * merging LATE — a replica keeps training while the sum of the last interval is still travelling, which is what
+#     hiding the all-reduce behind the next interval's training amounts to — breaks the band at 8 replicas however
+#     the late sum is applied (all rows: -0.017 hub, -0.085 uniform; only rows with u <= 256: -0.010 / -0.045;
+#     own change pre-weighted: -0.008 / -0.12); with u <= 64 it is neutral but then delays almost nothing (at this
+#     cadence an average row already has u ~ 500).  The delayed tier therefore exists (cold_delay=True, HOT_THETA)
+#     and is tested, but is OFF by default; what is hidden instead is the merge ARITHMETIC behind the wire time:
+#     the synchronous merge is pipelined over row ranges (ReplicaMerger.end_interval).
+# The arithmetic around the collectives is three fused kernels (csrc/n2v_merge.hip).
+HOT_BUDGET = 208.0
 HOT_THETA = 64.0
 STALENESS_BUDGET = 48.0
 MIN_WALKS_PER_LAUNCH = 8192  # informational: one wavefront trains one walk at a time; 5 356-walk launches still ran
@@ -224,7 +236,7 @@ class MergePlan:
     """Weights and tiers of one run: identical on every rank (derived from the global word counts)."""
 
     def __init__(self, counts, interval_tokens_global, world, window, negative, device, mode="hot",
-                 budget=HOT_BUDGET, theta=HOT_THETA, cold_delay=True):
+                 budget=HOT_BUDGET, theta=HOT_THETA, cold_delay=False):
         if mode not in ("hot", "delta", "avg"):
             raise ValueError("merge mode %r" % (mode,))
         b = {"hot": budget, "delta": float("inf"), "avg": 0.0}[mode]
@@ -354,6 +366,10 @@ class ReplicaMerger:
         out["merge"] += out["wait"]
         return out
 
+    def release(self):
+        """Drop the buffers (the timers stay readable)."""
+        self.xs = self.base = self.hot_wire = self.hot_views = self.cold_wire = self.cold_views = None
+
     def _wait_pending(self):
         if self.pending is None:
             return None
@@ -477,7 +493,7 @@ def _merge_setup(model, L, n_walks_global, world, syncs_per_epoch, merge, cold_d
 
 
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
-          merge="hot", overlap=True, cold_delay=True, ops=None):
+          merge="hot", overlap=True, cold_delay=False, ops=None):
     """Train `epochs` passes over this rank's walks.  With a communicator the replicas are merged
     `syncs_per_epoch` times per pass ("auto": auto_syncs) by a ReplicaMerger; returns the merger (None on one
     GPU) so that the caller can read its timers."""
@@ -540,7 +556,7 @@ class _SimGroup:
 
 
 def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="hot", epochs=1,
-                             cold_delay=True, wire_dtype=torch.bfloat16):
+                             cold_delay=False, wire_dtype=torch.bfloat16):
     """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens, shard_offset)` what
     rank r would hold.  Runs the schedule of `train` with one ReplicaMerger per replica — the same kernels, the
     same two tiers, the same one-interval delay of the cold rows — so the multi-GPU scheme can be scored for AUC

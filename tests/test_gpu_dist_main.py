@@ -51,7 +51,7 @@ n, stride, K = 5000, 128, 6
 g = torch.Generator(device="cpu").manual_seed(5)
 base0 = torch.randn(n, stride, generator=g).to(dev)
 counts = (torch.rand(n, generator=g) ** 8 * 5000 + 1).long()        # a few hot rows, many cold ones
-plan = sgns.MergePlan(counts.numpy(), 2.0e5, 2, 10, 5, dev)
+plan = sgns.MergePlan(counts.numpy(), 2.0e5, 2, 10, 5, dev, cold_delay=True)     # both tiers in play
 assert 0 < plan.n_hot[0] < n and plan.n_cold[0] > 0
 incr = (torch.randn(K, 2, n, stride, generator=g) * 0.01).to(dev)
 results = []

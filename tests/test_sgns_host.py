@@ -75,14 +75,14 @@ def test_merge_plan_tiers():
     counts = np.full(1000, 100, dtype=np.int64)
     counts[:5] = 200000                                   # five hubs
     T = counts.sum() / 200.0                              # tokens per interval
-    plan = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"))
+    plan = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"), budget=256.0, theta=256.0, cold_delay=True)
     assert plan.hot_rows[0].tolist() == [0, 1, 2, 3, 4] and set(range(5)) <= set(plan.hot_rows[1].tolist())
     assert plan.hot_pos[0][:5].tolist() == [0, 1, 2, 3, 4] and (plan.hot_pos[0][5:] == -1).all()
     assert plan.n_hot[0] == 5 and plan.n_cold[0] == 995
-    (w0, w1), (u0, u1) = sgns.merge_weights(counts, T, 8, 10, 5, torch.device("cpu"), with_u=True)
-    assert torch.equal(plan.w[0], w0) and bool((u0[:5] > sgns.HOT_THETA).all()) and bool((u0[5:] <= sgns.HOT_THETA).all())
+    (w0, w1), (u0, u1) = sgns.merge_weights(counts, T, 8, 10, 5, torch.device("cpu"), budget=256.0, with_u=True)
+    assert torch.equal(plan.w[0], w0) and bool((u0[:5] > 256).all()) and bool((u0[5:] <= 256).all())
     assert (plan.w[0][5:] == 1).all() and (plan.w[0][:5] < 0.2).all()
-    sync = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"), cold_delay=False)
+    sync = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"))        # default: no delayed tier
     assert sync.n_hot == [1000, 1000] and sync.n_cold == [0, 0]
     avg = sgns.MergePlan(counts, T, 8, 10, 5, torch.device("cpu"), mode="avg")
     assert torch.allclose(avg.w[0], torch.full((1000,), 1 / 8))
