@@ -91,13 +91,15 @@ int n2v_build_edge_tables(int64_t n_nodes, const int64_t* row_ptr, const int32_t
  * slots staged in LDS and larger ones built in place in the output, written once in the layout the walk reads:
  * exactly one of `thin` (16-B slots at thin[edge_off[e] ...]) and `fat` (32-B n2v_fat_slot at
  * fat[edge_off[e] ...], needs the walk records `recs` of n2v_build_edge_recs, whose table indices address `fat`)
- * is non-NULL.  With `fat` no thin copy of the edge tables has to exist.  src/node2vec.py:133-152,240-269.   */
+ * is non-NULL.  With `fat` no thin copy of the edge tables has to exist.  work_counter: uint64[1] set to 0 by the
+ * caller — tables are then handed to the wavefronts dynamically (sizes differ by three orders of magnitude on a
+ * power-law graph), and `order` is not needed; NULL: static assignment.  src/node2vec.py:133-152,240-269.      */
 struct n2v_fat_slot;
 int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_ptr, const int32_t* col, const double* w,
                                const int32_t* src_of, double p, double q, int32_t symmetric,
                                const int64_t* edge_off, const int32_t* order, int64_t e_begin, int64_t e_end,
                                const n2v_edge_rec* recs, n2v_alias_slot* thin, struct n2v_fat_slot* fat,
-                               int32_t* status, void* stream);
+                               int32_t* status, uint64_t* work_counter, void* stream);
 
 /* Walk records.  edge_off == NULL: first-order shortcut (p == q == 1), every record
  * points at dst's node table, slot = slot_base + row_ptr[dst].  Otherwise

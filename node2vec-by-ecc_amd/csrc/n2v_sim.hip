@@ -7,10 +7,13 @@
 //   * EPI_SCAN : appends the scores above a running threshold to a candidate buffer (global top-k), or
 //   * EPI_BLOCK: writes the row block once; one workgroup per row then selects by threshold or by an exact
 //                radix select of the k-th largest score, emitting in column (= list) order.
-// A genuine dense contraction in fp32 (the reference's float32 dot): vector FMA at the same peak as the fp32
-// MFMA, kept in fp32 so the top-k SETS can be compared with a CPU restatement.
+// A genuine dense contraction in fp32 (the reference's float32 dot): the dot-product forms ("cos", "pearson") run on
+// the matrix cores (sim_mfma_kernel, v_mfma_f32_32x32x2_f32: fp32 in and out, so the top-k SETS can be compared
+// with a CPU restatement); the Jensen-Shannon form is not a contraction and stays on the vector tile kernel.
 #include "n2v_common.h"
 #include "n2v_sim.h"
+
+#include <cstdlib>
 
 namespace {
 
@@ -153,6 +156,86 @@ __global__ void __launch_bounds__(256) sim_tile_kernel(TileArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- MFMA tile (dot)
+// 128x128 scores per workgroup, 64x64 per wavefront as 2x2 blocks of v_mfma_f32_32x32x2_f32 (fp32 in, fp32
+// accumulate: the reference's float32 dot, no reduced precision).  Operands staged k-major through LDS like the
+// vector kernel; per k-pair a wave issues 4 LDS reads for 4 MFMAs (8 192 FMAs), against 8 LDS floats per 16 FMAs
+// in the vector form — the matrix pipe is what a dense fp32 contraction is for on this chip.  Operand layout of
+// the instruction: lane l supplies A[m = l % 32][k = l / 32] and B[k = l / 32][n = l % 32]; accumulator register v
+// of lane l holds D[8 * (v / 4) + 4 * (l / 32) + (v % 4)][l % 32].
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int MT = 128;    // tile edge
+constexpr int MKC = 16;    // k-chunk per barrier
+constexpr int MLD = 132;   // LDS pitch: the two k-halves of a wave's store land 32 banks apart
+
+template <bool SCAN>
+__global__ void __launch_bounds__(256) sim_mfma_kernel(TileArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[MKC][MLD];
+    __shared__ __attribute__((aligned(16))) float Bs[MKC][MLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int64_t r0 = a.row_begin + (int64_t)blockIdx.y * MT, c0 = (int64_t)blockIdx.x * MT;
+    if (SCAN && a.upper && c0 + MT - 1 <= r0) return;
+    const int lrow = tid >> 1, kq = (tid & 1) * 8;
+    const int64_t ar = r0 + lrow, br = c0 + lrow;
+    const float* ap = a.A + ar * a.dpad + kq;
+    const float* bp = a.B + br * a.dpad + kq;
+    const bool a_ok = ar < a.row_end, b_ok = br < a.n_cols;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    const float4 z4 = {0, 0, 0, 0};
+    float4 a0 = z4, a1 = z4, b0 = z4, b1 = z4;
+    if (a_ok) { a0 = *reinterpret_cast<const float4*>(ap); a1 = *reinterpret_cast<const float4*>(ap + 4); }
+    if (b_ok) { b0 = *reinterpret_cast<const float4*>(bp); b1 = *reinterpret_cast<const float4*>(bp + 4); }
+    const int kh = lane >> 5, m = lane & 31;
+    for (int k0 = 0; k0 < a.dpad; k0 += MKC) {
+        __syncthreads();
+        As[kq + 0][lrow] = a0.x; As[kq + 1][lrow] = a0.y; As[kq + 2][lrow] = a0.z; As[kq + 3][lrow] = a0.w;
+        As[kq + 4][lrow] = a1.x; As[kq + 5][lrow] = a1.y; As[kq + 6][lrow] = a1.z; As[kq + 7][lrow] = a1.w;
+        Bs[kq + 0][lrow] = b0.x; Bs[kq + 1][lrow] = b0.y; Bs[kq + 2][lrow] = b0.z; Bs[kq + 3][lrow] = b0.w;
+        Bs[kq + 4][lrow] = b1.x; Bs[kq + 5][lrow] = b1.y; Bs[kq + 6][lrow] = b1.z; Bs[kq + 7][lrow] = b1.w;
+        __syncthreads();
+        if (k0 + MKC < a.dpad) {      // next chunk's rows travel while this one is multiplied
+            a0 = a1 = b0 = b1 = z4;
+            if (a_ok) { a0 = *reinterpret_cast<const float4*>(ap + k0 + MKC); a1 = *reinterpret_cast<const float4*>(ap + k0 + MKC + 4); }
+            if (b_ok) { b0 = *reinterpret_cast<const float4*>(bp + k0 + MKC); b1 = *reinterpret_cast<const float4*>(bp + k0 + MKC + 4); }
+        }
+#pragma unroll
+        for (int kk = 0; kk < MKC; kk += 2) {
+            const float av0 = As[kk + kh][wr * 64 + m], av1 = As[kk + kh][wr * 64 + 32 + m];
+            const float bv0 = Bs[kk + kh][wc * 64 + m], bv1 = Bs[kk + kh][wc * 64 + 32 + m];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc[1][1], 0, 0, 0);
+        }
+    }
+    const float tau = SCAN ? *a.tau : 0.f;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int64_t r = r0 + wr * 64 + bi * 32 + 8 * (v >> 2) + 4 * kh + (v & 3);
+                const int64_t c = c0 + wc * 64 + bj * 32 + m;
+                if (r >= a.row_end || c >= a.n_cols) continue;
+                const float s = acc[bi][bj][v];
+                if (SCAN) {
+                    if (!(s > tau) || (a.upper && c <= r)) continue;
+                    if (a.n_excl > 0 && key_in(a.excl, a.n_excl, r * a.n_cols + c)) continue;   // train edge (:74,:84)
+                    const int64_t idx = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(a.counter), 1ull);
+                    if (idx < a.capacity) { a.cand_score[idx] = s; a.cand_row[idx] = (int32_t)r; a.cand_col[idx] = (int32_t)c; }
+                } else {
+                    a.out[(r - a.row_begin) * a.ld + c] = (a.zero_diag_off >= 0 && c == r + a.zero_diag_off) ? 0.f : s;
+                }
+            }
+}
+
 // ---------------------------------------------------------------------------------------------- row selection
 // Ordered emission helper: every thread of the 256-thread workgroup passes `flag`; returns the thread's
 // position among the flagged threads of this call plus *base (shared running total, advanced by the call).
@@ -286,6 +369,9 @@ extern "C" int n2v_sim_prepare(const float* vec, int32_t stride, int32_t dim, co
     return n2v::check_launch("n2v_sim_prepare");
 }
 
+// N2V_SIM_VECTOR=1 runs the dot product on the vector-FMA tile kernel instead of the MFMA one (A/B in tools/sim_probe.py)
+static bool vector_fma_forced() { const char* e = getenv("N2V_SIM_VECTOR"); return e && e[0] == '1'; }
+
 static int tile_args_ok(const char* who, const float* A, const float* B, int64_t row_begin, int64_t n_rows, int64_t n_cols,
                         int32_t dpad) {
     if (row_begin < 0 || n_rows < 0 || n_cols < 0 || dpad < KC || (dpad % KC) != 0)
@@ -307,8 +393,10 @@ extern "C" int n2v_sim_block(const float* A, int64_t row_begin, int64_t n_rows, 
     a.A = A; a.B = B; a.row_begin = row_begin; a.row_end = row_begin + n_rows; a.n_cols = n_cols; a.dpad = dpad;
     a.out = out; a.ld = ld; a.zero_diag_off = zero_diag_off;
     const dim3 grid((unsigned)((n_cols + TILE - 1) / TILE), (unsigned)((n_rows + TILE - 1) / TILE));
+    const dim3 mgrid((unsigned)((n_cols + MT - 1) / MT), (unsigned)((n_rows + MT - 1) / MT));
     if (method == N2V_SIM_JSD) hipLaunchKernelGGL((sim_tile_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((sim_tile_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (vector_fma_forced()) hipLaunchKernelGGL((sim_tile_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((sim_mfma_kernel<false>), mgrid, dim3(256), 0, (hipStream_t)stream, a);
     return n2v::check_launch("n2v_sim_block");
 }
 
@@ -327,8 +415,10 @@ extern "C" int n2v_sim_topk_scan(const float* A, int64_t row_begin, int64_t row_
     a.upper = upper_triangle ? 1 : 0; a.tau = tau; a.excl = excl_keys; a.n_excl = n_excl;
     a.cand_score = cand_score; a.cand_row = cand_row; a.cand_col = cand_col; a.capacity = capacity; a.counter = counter;
     const dim3 grid((unsigned)((n_cols + TILE - 1) / TILE), (unsigned)((row_end - row_begin + TILE - 1) / TILE));
+    const dim3 mgrid((unsigned)((n_cols + MT - 1) / MT), (unsigned)((row_end - row_begin + MT - 1) / MT));
     if (method == N2V_SIM_JSD) hipLaunchKernelGGL((sim_tile_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((sim_tile_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (vector_fma_forced()) hipLaunchKernelGGL((sim_tile_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((sim_mfma_kernel<true>), mgrid, dim3(256), 0, (hipStream_t)stream, a);
     return n2v::check_launch("n2v_sim_topk_scan");
 }
 

@@ -46,7 +46,10 @@ struct TabArgs {
     n2v_alias_slot* thin;
     n2v_fat_slot* fat;
     int32_t* status;
+    unsigned long long* work;    // dynamic hand-out of tables (NULL: static grid-stride)
 };
+
+constexpr int kChunk = 16;       // tables a wave takes per visit to the shared counter
 
 __device__ __forceinline__ void wave_sync() {  // order this wave's LDS / global traffic between phases
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -199,8 +202,22 @@ __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
     n2v_alias_slot* Tl = lds + wv * kLdsSlots;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     bool zero = false;
-    for (int64_t i = a.e_begin + (int64_t)blockIdx.x * 4 + wv; i < a.e_end; i += n_waves) {
-        const int64_t e = a.order ? (int64_t)(uint32_t)uni(a.order[i]) : i;
+    // Tables are handed out kChunk at a time from a shared counter (table sizes span 10 ... 16 614 slots on C3, so
+    // a static assignment leaves the waves with the hubs as the tail); without a counter: static grid-stride.
+    int64_t i = a.e_begin + (int64_t)blockIdx.x * 4 + wv, chunk_end = 0;
+    for (;;) {
+        if (a.work) {
+            if (i >= chunk_end) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(a.work, (unsigned long long)kChunk);
+                i = a.e_begin + uni64((int64_t)b);
+                chunk_end = i + kChunk;
+            }
+        }
+        if (i >= a.e_end) break;
+        const int64_t i_cur = i;
+        i += a.work ? 1 : n_waves;
+        const int64_t e = a.order ? (int64_t)(uint32_t)uni(a.order[i_cur]) : i_cur;
         const int32_t src = uni(a.src_of[e]), dst = uni(a.col[e]);
         const int64_t base = uni64(a.row_ptr[dst]);
         const int K = uni((int)(a.row_ptr[dst + 1] - base));
@@ -230,7 +247,7 @@ extern "C" int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_pt
                                           const int32_t* src_of, double p, double q, int32_t symmetric,
                                           const int64_t* edge_off, const int32_t* order, int64_t e_begin, int64_t e_end,
                                           const n2v_edge_rec* recs, n2v_alias_slot* thin, n2v_fat_slot* fat,
-                                          int32_t* status, void* stream) {
+                                          int32_t* status, uint64_t* work_counter, void* stream) {
     if (n_nodes < 0 || e_begin < 0 || e_end < e_begin)
         return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: bad range [%lld, %lld)", (long long)e_begin, (long long)e_end);
     if (e_end == e_begin) return N2V_OK;
@@ -241,7 +258,8 @@ extern "C" int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_pt
     if (fat && !recs) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: fat output needs the edge records");
     if (fat && ((uintptr_t)fat & 31) != 0) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: fat slots not 32-byte aligned");
     if (!(p == p) || !(q == q)) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: p or q is NaN");
-    TabArgs a{row_ptr, col, w, src_of, p, q, symmetric, edge_off, order, e_begin, e_end, recs, thin, fat, status};
+    TabArgs a{row_ptr, col, w, src_of, p, q, symmetric, edge_off, order, e_begin, e_end, recs, thin, fat, status,
+              reinterpret_cast<unsigned long long*>(work_counter)};
     int64_t blocks = (e_end - e_begin + 3) / 4;
     if (blocks > 256 * 5 * 8) blocks = 256 * 5 * 8;   // 5 resident workgroups per CU by LDS; tables are handed out in a grid-stride loop
     if (fat) hipLaunchKernelGGL((edge_tables_wave_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

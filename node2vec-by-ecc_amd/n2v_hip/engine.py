@@ -100,12 +100,23 @@ class WalkEngine:
             if self.first_order:
                 self.edge_slots = self.node_slots
             else:
-                order = torch.argsort(kdst, descending=True).to(torch.int32)
-                src_of = torch.repeat_interleave(torch.arange(N, dtype=torch.int32, device=d), self.deg)
-                sym = 0 if csr.directed else 1
-                tick("order")
+                # the big buffers FIRST: on this stack a fresh multi-GB allocation that follows a device sort takes
+                # seconds (tools/alloc_probe.py: 58 GB in 0.000 s before, 3.06 s after torch.argsort of 2e7 keys —
+                # 1.45-1.63 s of round 1's 2.76 s preprocess), so nothing is sorted here any more: the wave kernel
+                # takes its tables from a shared counter instead of a size-ordered list
                 if want_thin:
                     self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
+                if want_fat:
+                    self.edge_fat = torch.empty((max(total, 1), 4), dtype=torch.int64, device=d)
+                tick("alloc")
+                src_of = torch.repeat_interleave(torch.arange(N, dtype=torch.int32, device=d), self.deg)
+                sym = 0 if csr.directed else 1
+                order = None
+                if builder == "lane":        # one lane per table: lanes of a wave should get tables of similar size
+                    order = torch.argsort(kdst, descending=True).to(torch.int32)
+                work = torch.zeros(2, dtype=torch.int64, device=d)
+                tick("src_of")
+                if want_thin:
                     if builder == "lane":
                         _lib.check(self.lib.n2v_build_edge_tables(
                             N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
@@ -114,12 +125,10 @@ class WalkEngine:
                     else:
                         _lib.check(self.lib.n2v_build_edge_tables_wave(
                             N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
-                            self.p, self.q, sym, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz, None,
-                            _lib.ptr(self.edge_slots), None, _lib.ptr(status), self._stream()))
+                            self.p, self.q, sym, _lib.ptr(self.edge_off), None, 0, nnz, None,
+                            _lib.ptr(self.edge_slots), None, _lib.ptr(status), work[0:].data_ptr(), self._stream()))
                     tick("edge_tables_thin")
                 if want_fat:
-                    self.edge_fat = torch.empty((max(total, 1), 4), dtype=torch.int64, device=d)
-                    tick("alloc_fat")
                     if builder == "lane":
                         assert want_thin, "the lane builder writes thin tables; fat ones are expanded from them"
                         _lib.check(self.lib.n2v_build_fat_slots(
@@ -128,8 +137,8 @@ class WalkEngine:
                     else:
                         _lib.check(self.lib.n2v_build_edge_tables_wave(
                             N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
-                            self.p, self.q, sym, _lib.ptr(self.edge_off), _lib.ptr(order), 0, nnz, _lib.ptr(self.recs),
-                            None, _lib.ptr(self.edge_fat), _lib.ptr(status), self._stream()))
+                            self.p, self.q, sym, _lib.ptr(self.edge_off), None, 0, nnz, _lib.ptr(self.recs),
+                            None, _lib.ptr(self.edge_fat), _lib.ptr(status), work[1:].data_ptr(), self._stream()))
                     tick("edge_tables_fat")
                 del order, src_of, kdst
             if want_fat and nnz > 0:
