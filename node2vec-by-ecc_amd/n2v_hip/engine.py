@@ -36,7 +36,15 @@ class WalkEngine:
         self.w = None if csr.w is None else torch.from_numpy(csr.w).to(d)
         self.start_order = torch.from_numpy(csr.start_order).to(d)
         self.deg = (self.row_ptr[1:] - self.row_ptr[:-1])
-        self.max_degree = int(self.deg.max().item()) if csr.n_nodes else 0
+        hdeg = np.diff(csr.row_ptr)
+        self.max_degree = int(hdeg.max()) if csr.n_nodes else 0     # host arithmetic: see preprocess() on why no device
+        # reduction / scan / sort may run before the big table allocation
+        if csr.nnz == 0:
+            self.total_edge_slots = 0
+        elif csr.directed:
+            self.total_edge_slots = int((np.bincount(csr.col, minlength=csr.n_nodes).astype(np.int64) * hdeg).sum())
+        else:
+            self.total_edge_slots = int((hdeg.astype(np.int64) ** 2).sum())   # sum over entries of deg(col[e])
         self.node_slots = None
         self.edge_slots = None
         self.edge_off = None
@@ -66,21 +74,8 @@ class WalkEngine:
         tick = self._phase_timer()
         self.node_slots = self.edge_slots = self.recs = self.node_fat = self.edge_fat = None
         with torch.cuda.device(d):
-            status = torch.zeros(1, dtype=torch.int32, device=d)
-            self.node_slots = torch.zeros((max(nnz, 1), 2), dtype=torch.int64, device=d)
-            _lib.check(self.lib.n2v_build_node_tables(
-                N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(self.node_slots),
-                _lib.ptr(status), self._stream()))
-            tick("node_tables")
             self.first_order = bool(first_order_shortcut and self.p == 1.0 and self.q == 1.0)
-            if self.first_order:
-                self.edge_off = None
-                total = nnz
-            else:
-                kdst = self.deg[self.col.long()]
-                self.edge_off = torch.zeros(nnz + 1, dtype=torch.int64, device=d)
-                torch.cumsum(kdst, 0, out=self.edge_off[1:])
-                total = int(self.edge_off[-1].item())
+            total = nnz if self.first_order else self.total_edge_slots
             self.total_slots = total
             free, _ = torch.cuda.mem_get_info(d)
             if fat == "auto":
@@ -91,6 +86,29 @@ class WalkEngine:
             if need > free - (1 << 30):
                 raise MemoryError("edge alias tables need %.1f GB (sum of deg^2 = %d slots), %.1f GB free"
                                   % (need / 1e9, total, free / 1e9))
+            # The big buffers FIRST, before any device scan / sort / reduction of this call: on this stack a fresh
+            # multi-GB allocation that follows such a kernel takes seconds (tools/alloc_probe.py: 58 GB in 0.000 s
+            # as the first thing, 3.06 s after a torch.argsort of 2e7 keys; round 1's preprocess spent 1.5-2.4 s of
+            # its 2.76 s there).  The slot count comes from host arithmetic on the CSR for the same reason.
+            if not self.first_order:
+                if want_thin:
+                    self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
+                if want_fat:
+                    self.edge_fat = torch.empty((max(total, 1), 4), dtype=torch.int64, device=d)
+            tick("alloc")
+            status = torch.zeros(1, dtype=torch.int32, device=d)
+            self.node_slots = torch.zeros((max(nnz, 1), 2), dtype=torch.int64, device=d)
+            _lib.check(self.lib.n2v_build_node_tables(
+                N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(self.node_slots),
+                _lib.ptr(status), self._stream()))
+            tick("node_tables")
+            if self.first_order:
+                self.edge_off = None
+            else:
+                kdst = self.deg[self.col.long()]
+                self.edge_off = torch.zeros(nnz + 1, dtype=torch.int64, device=d)
+                torch.cumsum(kdst, 0, out=self.edge_off[1:])
+                assert int(self.edge_off[-1].item()) == total, "host and device slot counts differ"
             # walk records first: they depend on the table OFFSETS only, and the fat slots embed them
             self.recs = torch.empty((max(nnz, 1), 4), dtype=torch.int32, device=d)
             _lib.check(self.lib.n2v_build_edge_recs(
@@ -100,15 +118,8 @@ class WalkEngine:
             if self.first_order:
                 self.edge_slots = self.node_slots
             else:
-                # the big buffers FIRST: on this stack a fresh multi-GB allocation that follows a device sort takes
-                # seconds (tools/alloc_probe.py: 58 GB in 0.000 s before, 3.06 s after torch.argsort of 2e7 keys —
-                # 1.45-1.63 s of round 1's 2.76 s preprocess), so nothing is sorted here any more: the wave kernel
-                # takes its tables from a shared counter instead of a size-ordered list
-                if want_thin:
-                    self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
-                if want_fat:
-                    self.edge_fat = torch.empty((max(total, 1), 4), dtype=torch.int64, device=d)
-                tick("alloc")
+                # nothing is sorted here: the wave kernel takes its tables from a shared counter instead of a
+                # size-ordered list
                 src_of = torch.repeat_interleave(torch.arange(N, dtype=torch.int32, device=d), self.deg)
                 sym = 0 if csr.directed else 1
                 order = None

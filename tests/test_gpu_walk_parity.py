@@ -440,9 +440,10 @@ def test_shards_reproduce_the_single_process_walks(n2v):
 def test_directed_sinks_sharded_and_pass_bound(n2v):
     """Directed graphs with reachable sinks in the reference-exact mode (SURVEY.md 8(a) row 6'): (1) the golden
     walks of er600_directed through simulate_walks_shard for 3- and 8-rank layouts (round 1 raised
-    NotImplementedError there); (2) a 5 000-node graph where a fifth of the nodes are sinks (> 10 % of the walks
-    end early): walks equal the C oracle's sequential result and the device-side offset resolution needs far
-    fewer passes than walks (round 1: up to one pass over ALL walks per early-ending walk)."""
+    NotImplementedError there); (2) a 5 000-node graph with 20 sinks (> 10 % of the walks end early): walks equal
+    the C oracle's sequential result and the device-side offset resolution needs about one pass (over a WINDOW)
+    per walk whose length changes when it is re-walked, ~2 x the share of early-ending walks — round 1 needed up to
+    one pass over ALL walks per early-ending walk."""
     import torch
     from n2v_hip import csr
     from oracle import c_oracle
@@ -471,7 +472,7 @@ def test_directed_sinks_sharded_and_pass_bound(n2v):
     rs = np.random.RandomState(8)
     N, M = 5000, 40000
     src, dst = rs.randint(0, N, M), rs.randint(0, N, M)
-    keep = (src % 5 != 0) & (src != dst)                   # nodes divisible by 5 have no out-edges
+    keep = (src % 250 != 0) & (src != dst)                 # nodes divisible by 250 have no out-edges: 20 sinks
     cg = csr.from_edges(src[keep], dst[keep], None, True)
     g2 = n2v.Graph.from_csr(cg, 0.5, 2.0, rng="numpy")
     g2.preprocess_transition_probs()
@@ -489,7 +490,7 @@ def test_directed_sinks_sharded_and_pass_bound(n2v):
     early = float((ol < L).mean())
     assert early > 0.10, early
     print("directed sinks: %d walks, %.0f%% end early, %d passes" % (W, 100 * early, g2.stream_passes))
-    assert g2.stream_passes < 0.5 * W, (g2.stream_passes, W)
+    assert g2.stream_passes < 0.35 * W, (g2.stream_passes, W)
 
 
 def test_randomised_parity_sweep(n2v):
