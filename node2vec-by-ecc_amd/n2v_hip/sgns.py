@@ -19,12 +19,19 @@ import torch
 from . import _lib
 
 UPDATE_MODES = {"plain": 0, "agent": 1, "atomic": 2}  # N2V_SGNS_* of include/n2v_hip.h
-# update_mode="auto": lossless memory-side atomics for small vocabularies, agent-scope
-# load/store above this many rows.  Measured (tools/mode_auc_probe.py, hub-heavy community graphs,
-# link-prediction AUC, two seeds each): 200k nodes atomic 0.87951 / agent 0.87948; 1M nodes atomic
-# 0.87918 / agent 0.88020 — inside the +-0.002 band at 1.6-2.2x the pair rate; at 3000 nodes the
-# agent mode drifts by +0.002 and more (every row is hot), so small tables keep the atomics.
+# update_mode="auto": lossless memory-side atomics unless the vocabulary has at least AUTO_AGENT_MIN_WORDS rows AND
+# the corpus holds at least AUTO_AGENT_MIN_TOKENS_PER_WORD tokens per row; then agent-scope load/store (1.6-2.2x the
+# pair rate).  Measured (link-prediction AUC on hub-heavy community graphs): 10 walks of 80 per node (800 tokens per
+# row) — 200k nodes atomic 0.87951 / agent 0.87948; 1M nodes 0.87918 / 0.88020; 131 072 nodes atomic 0.87593 / agent
+# 0.87621 against 0.87752 of the 12-thread CPU comparator: the two modes are indistinguishable and inside the +-0.002
+# band.  But the agent mode's lost updates (a read-modify-write of a row can lose a concurrent one) hit hardest while
+# the vectors are still growing: on the same 131 072-node graph with the main_link defaults of src/settings.py, 5 walks
+# of 40 (200 tokens per row), agent trails the comparator by 0.005 (0.84200 vs 0.84716; atomic 0.84666), and after
+# 2 walks of 40 by 0.24 (0.547 vs 0.787; atomic 0.784) — tests/probes/agent_band_probe.py,
+# profiles/r02/logs/agent_band_probe.log.  At 3000 nodes the agent mode drifts by +0.002 and more whatever the corpus
+# (every row is hot).  So short corpora and small tables keep the atomics.
 AUTO_AGENT_MIN_WORDS = 1 << 17
+AUTO_AGENT_MIN_TOKENS_PER_WORD = 600
 MAX_WORDS_IN_BATCH = 10000  # gensim: words per job; alpha is stepped once per job
 LUT_BITS = 20
 
@@ -80,10 +87,9 @@ class SgnsModel:
         self.stride = _row_stride(self.dim)
         self.window, self.negative = int(window), int(negative)
         self.alpha, self.min_alpha, self.sample, self.seed = float(alpha), float(min_alpha), sample, int(seed)
-        if update_mode == "auto":
-            update_mode = "agent" if int(n_words) >= AUTO_AGENT_MIN_WORDS else "atomic"
-        self.update_mode_name = update_mode
-        self.update_mode = UPDATE_MODES[update_mode] | (4 if share_negatives else 0)  # N2V_SGNS_SHARE_NEGATIVES
+        self._auto_mode = update_mode == "auto"     # resolved by build_vocab, which knows the corpus size
+        self._share = 4 if share_negatives else 0   # N2V_SGNS_SHARE_NEGATIVES
+        self._set_mode("atomic" if self._auto_mode else update_mode)
         d = self.device
         self.syn0 = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
         self.syn1neg = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
@@ -91,6 +97,10 @@ class SgnsModel:
         self.counts = None
         self.sample_int = self.cum_table = self.lut = None
         self.reset_weights()
+
+    def _set_mode(self, name):
+        self.update_mode_name = name
+        self.update_mode = UPDATE_MODES[name] | self._share
 
     def _stream(self):
         return _lib.stream_ptr(self.device)
@@ -110,6 +120,10 @@ class SgnsModel:
         else:
             counts_t = torch.as_tensor(counts, dtype=torch.int64, device=d)
         self.counts = counts_t.cpu().numpy()
+        if self._auto_mode:
+            big = self.n_words >= AUTO_AGENT_MIN_WORDS
+            long_corpus = float(self.counts.sum()) >= AUTO_AGENT_MIN_TOKENS_PER_WORD * self.n_words
+            self._set_mode("agent" if (big and long_corpus) else "atomic")
         sample_int, cum = vocab_tables(self.counts, self.sample)
         self.sample_int = None if sample_int is None else torch.from_numpy(sample_int.view(np.int32)).to(d)
         self.cum_table = torch.from_numpy(cum.view(np.int32)).to(d)
