@@ -383,5 +383,8 @@ def test_add_user_edges_changes_only_the_hits_input(tmp_path):
         wlk = tok[off[i]:off[i + 1]]
         for x, y in zip(wlk[:-1], wlk[1:]):
             assert set(g.col[g.row_ptr[x]:g.row_ptr[x + 1]]) & set(g.col[g.row_ptr[y]:g.row_ptr[y + 1]])
-    with pytest.raises(NotImplementedError):
-        bt.add_user_edge(args, gul, sim_method="pearson")
+    # the other similarities of src/bine_train.py:55-71 run on the same kernels; an unknown one is refused
+    n_p = bt.add_user_edge(args, gul, sim_method="pearson")
+    assert 0 < n_p <= g.n_u * k
+    with pytest.raises(ValueError):
+        bt.add_user_edge(args, gul, sim_method="manhattan")
