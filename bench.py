@@ -473,7 +473,7 @@ def main():
                           "algorithmic_bytes_per_unit": WALK_BYTES_PER_STEP, "unit_name": "walk step",
                           "launch_ms": walk_launch_s * 1e3},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
         t0 = time.perf_counter()
         ns = min(32000, n_local)
         result.update(cpu_baselines(cg, p, q, walks[:ns].cpu().numpy(), lens[:ns].cpu().numpy(),
