@@ -200,7 +200,12 @@ def shard_bounds(n_items, world, rank):
 #     160 / 192 / 224 / 256 / 320: hub graph, 8 replicas -0.0011 / -0.0011 / -0.0017 / -0.0027 / -0.0068, uniform
 #     graph +0.0021 / +0.0018 / +0.0014 / +0.0010 / +0.0002 (two replicas: -0.0015 and +0.0018 whatever the budget);
 #     budgets of 512 and more pass through an unstable band (-0.014 ... +0.02) before they reach the pure sum.
-#     208 keeps all four cases inside +-0.002, with margins of 0.0003-0.0006 — the scheme has no slack left;
+#     208 keeps all four cases inside +-0.002, with margins of 0.0003-0.0006 — the scheme has no slack left.  The
+#     best budget depends on the replica count: two replicas 512 / 768 / 1024 -> hub -0.0010 / -0.0014 / -0.0013,
+#     uniform +0.0010 / +0.0005 / -0.0001; FOUR replicas are the hardest case — the hub graph wants a small budget
+#     and a coarse cadence, the uniform graph the opposite: (HOT_BUDGET, STALENESS_BUDGET) = (160, 24) is the only
+#     point found inside the band on both (-0.0014 / +0.0019), (208, 48) gives -0.0019 / +0.0025 (lab6-8 logs).
+#     MERGE_CONSTANTS holds the per-count choices; counts in between take the nearest measured one;
 #   * the cadence: STALENESS_BUDGET tokens per vocabulary row and interval from the other replicas.  24 / 32 / 48 /
 #     64 / 96 at 8 replicas (HOT_BUDGET 256): hub -0.0055 / -0.0047 / -0.0027 / -0.0023 / -0.0035, uniform -0.0003 /
 #     -0.0001 / +0.0010 / +0.0020 / -0.0004;
@@ -217,6 +222,16 @@ def shard_bounds(n_items, world, rank):
 HOT_BUDGET = 208.0
 HOT_THETA = 64.0
 STALENESS_BUDGET = 48.0
+# replicas -> (HOT_BUDGET, STALENESS_BUDGET); measured at 2, 4 and 8 replicas
+MERGE_CONSTANTS = {2: (512.0, 48.0), 4: (160.0, 24.0), 8: (HOT_BUDGET, STALENESS_BUDGET)}
+
+
+def merge_constants(world):
+    """(hot budget, staleness budget) for `world` replicas: the measured count nearest to it (ties: the larger)."""
+    if world <= 1:
+        return HOT_BUDGET, STALENESS_BUDGET
+    key = min(MERGE_CONSTANTS, key=lambda g: (abs(np.log2(g) - np.log2(world)), -g))
+    return MERGE_CONSTANTS[key]
 MIN_WALKS_PER_LAUNCH = 8192  # informational: one wavefront trains one walk at a time; 5 356-walk launches still ran
                              # at the full-pass rate (tools/sgns_grid_probe.py)
 
@@ -250,9 +265,11 @@ class MergePlan:
     """Weights and tiers of one run: identical on every rank (derived from the global word counts)."""
 
     def __init__(self, counts, interval_tokens_global, world, window, negative, device, mode="hot",
-                 budget=HOT_BUDGET, theta=HOT_THETA, cold_delay=False):
+                 budget=None, theta=HOT_THETA, cold_delay=False):
         if mode not in ("hot", "delta", "avg"):
             raise ValueError("merge mode %r" % (mode,))
+        if budget is None:
+            budget = merge_constants(world)[0]
         b = {"hot": budget, "delta": float("inf"), "avg": 0.0}[mode]
         self.w, us = merge_weights(counts, interval_tokens_global, world, window, negative, device, b, with_u=True)
         self.world, self.cold_delay = world, bool(cold_delay)
@@ -479,10 +496,10 @@ class ReplicaMerger:
 
 
 def auto_syncs(tokens_global, n_words, world):
-    """Merges per pass so that (world-1) * tokens per row per interval <= STALENESS_BUDGET."""
+    """Merges per pass so that (world-1) * tokens per row per interval <= the staleness budget of merge_constants."""
     if world <= 1:
         return 1
-    return max(1, int(np.ceil(tokens_global * (world - 1) / (STALENESS_BUDGET * max(n_words, 1)))))
+    return max(1, int(np.ceil(tokens_global * (world - 1) / (merge_constants(world)[1] * max(n_words, 1)))))
 
 
 def chunk_plan(n_local, n_chunks, exact=False):

@@ -276,8 +276,12 @@ def _band_case(kind):
     return _BAND_CASES[kind]
 
 
-@pytest.mark.parametrize("G", [1, 2, 8])
-@pytest.mark.parametrize("kind", ["uniform", "hub"])
+_EDGE = pytest.mark.xfail(strict=False, reason="four replicas on the uniform graph: +0.0019 measured, 0.0001 inside the band — "
+                                                 "the one case of the merge scheme without any slack (n2v_hip/sgns.py)")
+
+
+@pytest.mark.parametrize("kind,G", [("uniform", 1), ("uniform", 2), pytest.param("uniform", 4, marks=_EDGE), ("uniform", 8),
+                                    ("hub", 1), ("hub", 2), ("hub", 4), ("hub", 8)])
 def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, kind, G):
     """The multi-GPU scheme (start-vertex shards, one replica per rank, 'hot'-weighted merges at the auto_syncs
     cadence, synchronous merges, bf16 wire) scored on ONE GPU by training G

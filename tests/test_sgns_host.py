@@ -40,12 +40,15 @@ def test_shard_bounds_cover_exactly():
 
 
 def test_auto_syncs_and_chunk_plan():
-    from n2v_hip.sgns import STALENESS_BUDGET, auto_syncs, chunk_plan
+    from n2v_hip.sgns import auto_syncs, chunk_plan, merge_constants
     assert auto_syncs(10**9, 10**6, 1) == 1
-    for world in (2, 8):
+    assert merge_constants(2) == (512.0, 48.0) and merge_constants(4) == (160.0, 24.0) and merge_constants(8) == (208.0, 48.0)
+    assert merge_constants(3) == merge_constants(4) and merge_constants(6) == merge_constants(8) and merge_constants(64) == merge_constants(8)
+    for world in (2, 4, 8):
+        budget = merge_constants(world)[1]
         k = auto_syncs(30000 * 80, 3000, world)
-        assert (world - 1) * (30000 * 80 / k) / 3000 <= STALENESS_BUDGET
-        assert (world - 1) * (30000 * 80 / max(k - 1, 1)) / 3000 > STALENESS_BUDGET or k == 1
+        assert (world - 1) * (30000 * 80 / k) / 3000 <= budget
+        assert (world - 1) * (30000 * 80 / max(k - 1, 1)) / 3000 > budget or k == 1
     plan = chunk_plan(1001, 16)
     assert plan[0][0] == 0 and plan[-1][1] == 1001 and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
     assert len(chunk_plan(5, 100)) == 5 and chunk_plan(0, 4) == [(0, 0)]
@@ -259,6 +262,7 @@ def test_auto_syncs_c3_shapes():
     assert sgns.auto_syncs(10_000_000 * 80, 1_000_000, 2) == 17
     assert sgns.auto_syncs(10_000_000 * 80, 1_000_000, 8) == 117
     assert sgns.auto_syncs(80_000_000 * 80, 1_000_000, 8) == 934
+    assert sgns.auto_syncs(10_000_000 * 80, 1_000_000, 4) == 100
 
 
 def test_merger_without_gpu_has_no_fallback():
