@@ -471,7 +471,12 @@ def main():
                           "frac": walk_bytes_launch / walk_launch_s / 1e9 / HBM_PEAK_GBS,
                           "traffic": (traffic or {}).get("walk_kernel"), "traffic_source": traffic_source,
                           "algorithmic_bytes_per_unit": WALK_BYTES_PER_STEP, "unit_name": "walk step",
-                          "launch_ms": walk_launch_s * 1e3},
+                          "launch_ms": walk_launch_s * 1e3,
+                          # one 64-B request per step; the fabric serves ~5.05e10 random requests/s from a table of this
+                          # size (tools/lab/gather_lab2.hip, profiles/r02/logs/lab2_gather2.jsonl): the ceiling of a
+                          # one-gather-per-step walk is 5.05e10 x 36 B / 8 TB/s = 22.7 % by this accounting
+                          "request_ceiling_steps_per_s": 5.05e10,
+                          "frac_of_request_ceiling": float(steps_done.item()) / K / walk_launch_s / 5.05e10},
     }
     if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
         t0 = time.perf_counter()

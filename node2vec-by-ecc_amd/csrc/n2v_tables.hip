@@ -17,8 +17,12 @@
 // chip's random-request rate (tools/lab: ~5e10 64-B requests/s): 0.33 s for the 1.83e9 slots of C3.
 // Compile with -ffp-contract=off (separately rounded divide / multiply / adds as in the reference).
 #include "n2v_common.h"
+#include "n2v_wave_table.h"
 
 namespace {
+
+using n2v::uni;
+using n2v::uni64;
 
 constexpr int kLdsSlots = 512;   // 8 KiB per wave, 32 KiB per 4-wave workgroup -> 5 workgroups per CU
 
@@ -33,12 +37,8 @@ struct fat_build_slot {
 static_assert(sizeof(fat_build_slot) == sizeof(n2v_fat_slot), "fat slot is 32 bytes");
 
 struct TabArgs {
-    const int64_t* row_ptr;
-    const int32_t* col;
-    const double* w;
+    n2v::RowCtx g;
     const int32_t* src_of;
-    double p, q;
-    int32_t symmetric;
     const int64_t* edge_off;
     const int32_t* order;
     int64_t e_begin, e_end;
@@ -50,131 +50,6 @@ struct TabArgs {
 };
 
 constexpr int kChunk = 16;       // tables a wave takes per visit to the shared counter
-
-__device__ __forceinline__ void wave_sync() {  // order this wave's LDS / global traffic between phases
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-// wave-uniform values that arrive through vector registers: make them scalar for the compiler, so the serial
-// loops branch on SCC and keep their counters in SGPRs
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int64_t uni64(int64_t v) {
-    return ((int64_t)uni((int)(v >> 32)) << 32) | (uint32_t)uni((int)v);
-}
-__device__ __forceinline__ double unid(double v) {
-    return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v)));
-}
-__device__ __forceinline__ double readlane_f64(double v, int j) {  // j wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-    return __hiloint2double(hi, lo);
-}
-
-// Builds the table of (src -> dst) in T[0..K): afterwards T[k].q / T[k].J are q[k] / J[k] of alias_setup.
-// Returns false when the weights sum to 0 (the reference raises ZeroDivisionError, :150).
-template <typename Slot>
-__device__ __forceinline__ bool build_edge_table(const TabArgs& a, Slot* T, int32_t src, int64_t base, int K, int lane) {
-    // ---- 1. unnormalised weights in parallel (:142-148); has_edge(nbr, src) is "nbr in row(src)" on an undirected
-    //         graph, so all lanes probe ONE row
-    for (int k = lane; k < K; k += 64) {
-        const int32_t nb = a.col[base + k];
-        const double wt = a.w ? a.w[base + k] : 1.0;
-        double u;
-        if (nb == src) u = wt / a.p;
-        else if (a.symmetric ? n2v::row_contains(a.row_ptr, a.col, src, nb) : n2v::row_contains(a.row_ptr, a.col, nb, src)) u = wt;
-        else u = wt / a.q;
-        T[k].q = u;
-    }
-    wave_sync();
-    // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149): 64 values per coalesced load, consumed
-    //         in order through v_readlane by every lane alike
-    double norm = 0.0;
-    for (int c = 0; c < K; c += 64) {
-        const double v = (c + lane < K) ? T[c + lane].q : 0.0;
-        const int cnt = min(64, K - c);
-        for (int j = 0; j < cnt; ++j) norm = norm + readlane_f64(v, j);
-    }
-    norm = unid(norm);
-    if (norm == 0.0) return false;
-    // ---- 3. q = K * (u / norm) (:150 then :253, two roundings) and the two index stacks in index order
-    //         (:252-257): `smaller` grows up from slot 0, `larger` down from slot K-1
-    const double Kd = (double)K;
-    int ns = 0, nl = 0;
-    for (int c = 0; c < K; c += 64) {
-        const int k = c + lane;
-        const bool valid = k < K;
-        double qk = 0.0;
-        if (valid) {
-            qk = Kd * (T[k].q / norm);
-            T[k].q = qk;
-            T[k].J = 0;
-        }
-        const bool is_small = valid && (qk < 1.0);
-        const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
-        const unsigned long long below = (1ULL << lane) - 1ULL;
-        if (is_small) T[ns + __popcll(ms & below)].aux = k;
-        else if (valid) T[K - (nl + __popcll(ml & below) + 1)].aux = k;
-        ns += __popcll(ms);
-        nl += __popcll(ml);
-    }
-    ns = uni(ns);
-    nl = uni(nl);
-    wave_sync();
-    // ---- 4. pairing (:259-268).  Both memory stacks only ever hold entries of the initial classification, popped
-    //         in a fixed order and never modified before they are popped: they are streamed 64 entries at a time,
-    //         one per lane, and handed to the (wave-uniform) loop by v_readlane.
-    int mem_s = ns, mem_l = nl;
-    bool hasS = false, hasL = false;
-    int rsi = 0, rli = 0;
-    double rsq = 0.0, rlq = 0.0;
-    int si = 0, s_cnt = 0, s_pos = 0, li = 0, l_cnt = 0, l_pos = 0;
-    double sq = 0.0, lq = 0.0;
-    while ((mem_s > 0 || hasS) && (mem_l > 0 || hasL)) {
-        int small, large;
-        double qs, ql;
-        if (hasS) {                       // smaller.pop(): the element the previous iteration pushed
-            small = rsi; qs = rsq; hasS = false;
-            if (lane == 0) T[small].q = qs;
-        } else {
-            if (s_pos == s_cnt) {         // next <= 64 entries of `smaller`, in pop order (top = position mem_s-1)
-                const int pos = mem_s - 1 - lane;
-                if (pos >= 0) { si = T[pos].aux; sq = T[si].q; }
-                s_cnt = min(64, mem_s);
-                s_pos = 0;
-            }
-            small = __builtin_amdgcn_readlane(si, s_pos);
-            qs = readlane_f64(sq, s_pos);
-            ++s_pos;
-            --mem_s;
-        }
-        if (hasL) {                       // larger.pop()
-            large = rli; ql = rlq; hasL = false;
-        } else {
-            if (l_pos == l_cnt) {         // next <= 64 entries of `larger` (top = position K-mem_l, then upwards)
-                const int pos = K - mem_l + lane;
-                if (pos < K) { li = T[pos].aux; lq = T[li].q; }
-                l_cnt = min(64, mem_l);
-                l_pos = 0;
-            }
-            large = __builtin_amdgcn_readlane(li, l_pos);
-            ql = readlane_f64(lq, l_pos);
-            ++l_pos;
-            --mem_l;
-        }
-        if (lane == 0) T[small].J = large;          // :263
-        double t = ql + qs;                          // :264, left to right
-        t = t - 1.0;
-        if (uni((int)(t < 1.0))) { hasS = true; rsi = large; rsq = t; }
-        else { hasL = true; rli = large; rlq = t; }
-    }
-    if (lane == 0) {
-        if (hasS) T[rsi].q = rsq;
-        if (hasL) T[rli].q = rlq;
-    }
-    wave_sync();
-    return true;
-}
 
 // fat[t0 + k] = {q[k], rec(base + k), rec(base + J[k])} (include/n2v_hip.h, n2v_fat_slot)
 template <typename Slot>
@@ -218,23 +93,23 @@ __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
         const int64_t i_cur = i;
         i += a.work ? 1 : n_waves;
         const int64_t e = a.order ? (int64_t)(uint32_t)uni(a.order[i_cur]) : i_cur;
-        const int32_t src = uni(a.src_of[e]), dst = uni(a.col[e]);
-        const int64_t base = uni64(a.row_ptr[dst]);
-        const int K = uni((int)(a.row_ptr[dst + 1] - base));
+        const int32_t src = uni(a.src_of[e]), dst = uni(a.g.col[e]);
+        const int64_t base = uni64(a.g.row_ptr[dst]);
+        const int K = uni((int)(a.g.row_ptr[dst + 1] - base));
         if (K == 0) continue;
         const int64_t t0 = uni64(a.edge_off[e]);
         if (K <= kLdsSlots) {
-            if (!build_edge_table(a, Tl, src, base, K, lane)) { zero = true; continue; }
+            if (!n2v::wave_build_table(a.g, Tl, src, base, K, lane)) { zero = true; continue; }
             if (FAT) emit_fat(a, Tl, t0, base, K, lane);
             else for (int k = lane; k < K; k += 64) { n2v_alias_slot s = Tl[k]; s.aux = 0; a.thin[t0 + k] = s; }
             __builtin_amdgcn_wave_barrier();   // the LDS slice is reused by the next table
         } else if (FAT) {
             fat_build_slot* Tg = reinterpret_cast<fat_build_slot*>(a.fat + t0);
-            if (!build_edge_table(a, Tg, src, base, K, lane)) { zero = true; continue; }
+            if (!n2v::wave_build_table(a.g, Tg, src, base, K, lane)) { zero = true; continue; }
             emit_fat(a, Tg, t0, base, K, lane);  // in place: slot k is rewritten from its own q, J only
         } else {
             n2v_alias_slot* Tg = a.thin + t0;
-            if (!build_edge_table(a, Tg, src, base, K, lane)) { zero = true; continue; }
+            if (!n2v::wave_build_table(a.g, Tg, src, base, K, lane)) { zero = true; continue; }
             for (int k = lane; k < K; k += 64) Tg[k].aux = 0;
         }
     }
@@ -258,7 +133,7 @@ extern "C" int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_pt
     if (fat && !recs) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: fat output needs the edge records");
     if (fat && ((uintptr_t)fat & 31) != 0) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: fat slots not 32-byte aligned");
     if (!(p == p) || !(q == q)) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: p or q is NaN");
-    TabArgs a{row_ptr, col, w, src_of, p, q, symmetric, edge_off, order, e_begin, e_end, recs, thin, fat, status,
+    TabArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, src_of, edge_off, order, e_begin, e_end, recs, thin, fat, status,
               reinterpret_cast<unsigned long long*>(work_counter)};
     int64_t blocks = (e_end - e_begin + 3) / 4;
     if (blocks > 256 * 5 * 8) blocks = 256 * 5 * 8;   // 5 resident workgroups per CU by LDS; tables are handed out in a grid-stride loop

@@ -10,25 +10,24 @@
 // One wavefront owns one walk.  Per step the wave
 //   1. gathers cur's row (ids, weights) cooperatively and classifies every neighbour
 //      (== prev: w/p; has_edge(nbr, prev): w; else w/q — src/node2vec.py:142-148) in parallel,
-//   2. has ONE lane do the two inherently serial pieces exactly as the reference does — the
-//      left-to-right fp64 sum (:149) and Vose's stack pairing (:259-268),
+//   2. runs the two inherently serial pieces in the reference's order — the left-to-right fp64 sum (:149) and
+//      Vose's stack pairing (:259-268) — fed from registers (n2v_wave_table.h, shared with the table builder),
 //   3. normalises (divide, then multiply by K) in parallel again, and draws.
 // The table lives in the wave's slice of LDS while K <= kLdsSlots and in a per-wave global
 // scratch row of max_degree slots otherwise.  Serial chains of many waves interleave on a
 // SIMD, so throughput comes from occupancy; -ffp-contract=off keeps every rounding separate.
 #include "n2v_common.h"
-#include "n2v_vose.h"
+#include "n2v_wave_table.h"
 
 namespace {
 
 constexpr int kLdsSlots = 512;  // 8 KiB of LDS per wave, 32 KiB per 4-wave workgroup
 
+using n2v::uni;
+using n2v::uni64;
+
 struct OtfArgs {
-    const int64_t* row_ptr;
-    const int32_t* col;
-    const double* w;
-    double p, q;
-    int32_t symmetric;  // undirected graph: has_edge(nbr, prev) == nbr in row(prev), one shared row
+    n2v::RowCtx g;      // CSR, p, q, symmetric
     const int32_t* starts;
     int64_t n_starts, pos_begin, pos_count, round_begin, n_local;
     int32_t L;
@@ -42,130 +41,6 @@ struct OtfArgs {
     int32_t* lens;
     int32_t* status;
 };
-
-__device__ __forceinline__ void wave_sync() {  // order this wave's LDS / scratch traffic between phases
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// Values that are equal in all 64 lanes by construction but reach us through vector loads or
-// vector arithmetic: moving them through v_readfirstlane makes them scalar for the compiler, so
-// the serial loops below branch on SCC and keep their counters in SGPRs instead of running as
-// exec-masked "divergent" loops (which cost ~60 instructions per slot instead of ~15).
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int64_t uni64(int64_t v) {
-    return ((int64_t)uni((int)(v >> 32)) << 32) | (uint32_t)uni((int)v);
-}
-__device__ __forceinline__ double unid(double v) {
-    return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v)));
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int j) {  // j wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-    return __hiloint2double(hi, lo);
-}
-
-// One step's table for (prev -> cur); prev < 0 means the first step (node table, :13-25).
-// The two inherently serial pieces keep the reference's order of operations but are fed
-// cooperatively: 64 slots are loaded by the 64 lanes in one coalesced access and then consumed
-// one after the other through v_readlane, by every lane redundantly (uniform control flow), so the
-// serial chain is two fp64 adds per slot instead of a dependent memory round trip per slot.
-template <typename SlotPtr>
-__device__ __forceinline__ bool build_table(const OtfArgs& a, SlotPtr T, int32_t prev, int64_t base, int K, int lane) {
-    // ---- 1. unnormalised weights, in parallel (:142-148)
-    for (int k = lane; k < K; k += 64) {
-        const int32_t nb = a.col[base + k];
-        const double wt = a.w ? a.w[base + k] : 1.0;
-        double u;
-        if (prev < 0) u = wt;
-        else if (nb == prev) u = wt / a.p;
-        else if (a.symmetric ? n2v::row_contains(a.row_ptr, a.col, prev, nb)   // every lane probes prev's row
-                             : n2v::row_contains(a.row_ptr, a.col, nb, prev)) u = wt;
-        else u = wt / a.q;
-        T[k].q = u;
-    }
-    wave_sync();
-    // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149 / :22)
-    double norm = 0.0;
-    for (int c = 0; c < K; c += 64) {
-        const double v = (c + lane < K) ? T[c + lane].q : 0.0;
-        const int cnt = min(64, K - c);
-        for (int j = 0; j < cnt; ++j) norm = norm + readlane_f64(v, j);
-    }
-    norm = unid(norm);
-    if (norm == 0.0) return false;  // ZeroDivisionError in the reference (:150/:23)
-    // ---- 3. q = K * (u / norm) and the two index stacks, in parallel (:150, :252-257): `smaller`
-    //         grows up from slot 0, `larger` down from slot K-1, both in index order
-    const double Kd = (double)K;
-    int ns = 0, nl = 0;
-    for (int c = 0; c < K; c += 64) {
-        const int k = c + lane;
-        const bool valid = k < K;
-        double qk = 0.0;
-        if (valid) {
-            qk = Kd * (T[k].q / norm);
-            T[k].q = qk;
-            T[k].J = 0;
-        }
-        const bool is_small = valid && (qk < 1.0);
-        const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
-        const unsigned long long below = (1ULL << lane) - 1ULL;
-        if (is_small) T[ns + __popcll(ms & below)].aux = k;
-        else if (valid) T[K - (nl + __popcll(ml & below) + 1)].aux = k;
-        ns += __popcll(ms);
-        nl += __popcll(ml);
-    }
-    ns = uni(ns);
-    nl = uni(nl);
-    wave_sync();
-    // ---- 4. pairing (:259-268).  A pushed element is always the next one popped from its stack, so
-    //         it stays in registers; the memory `smaller` stack is streamed 64 entries at a time.
-    int mem_s = ns, mem_l = nl;
-    bool hasS = false, hasL = false;
-    int rsi = 0, rli = 0;
-    double rsq = 0.0, rlq = 0.0;
-    int ci = 0, c_cnt = 0, c_pos = 0;
-    double cq = 0.0;
-    while ((mem_s > 0 || hasS) && (mem_l > 0 || hasL)) {
-        int small, large;
-        double qs, ql;
-        if (hasS) {
-            small = rsi; qs = rsq; hasS = false;
-            if (lane == 0) T[small].q = qs;
-        } else {
-            if (c_pos == c_cnt) {  // next up-to-64 entries of `smaller`, in pop order, one per lane
-                const int pos = mem_s - 1 - lane;
-                if (pos >= 0) { ci = T[pos].aux; cq = T[ci].q; }
-                c_cnt = min(64, mem_s);
-                c_pos = 0;
-            }
-            small = __builtin_amdgcn_readlane(ci, c_pos);
-            qs = readlane_f64(cq, c_pos);
-            ++c_pos;
-            --mem_s;
-        }
-        if (hasL) {
-            large = rli; ql = rlq; hasL = false;
-        } else {
-            large = uni(T[K - mem_l].aux);
-            --mem_l;
-            ql = unid(T[large].q);
-        }
-        if (lane == 0) T[small].J = large;
-        double t = ql + qs;  // left to right (:264)
-        t = t - 1.0;
-        if (uni((int)(t < 1.0))) { hasS = true; rsi = large; rsq = t; }
-        else { hasL = true; rli = large; rlq = t; }
-    }
-    if (lane == 0) {
-        if (hasS) T[rsi].q = rsq;
-        if (hasL) T[rli].q = rlq;
-    }
-    wave_sync();
-    return true;
-}
 
 __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
     __shared__ n2v_alias_slot lds[4 * kLdsSlots];
@@ -191,12 +66,12 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
         int32_t len = 1;
         bool failed = false;
         for (; len < L; ++len) {
-            const int64_t base = uni64(a.row_ptr[cur]);
-            const int K = uni((int)(a.row_ptr[cur + 1] - base));
+            const int64_t base = uni64(a.g.row_ptr[cur]);
+            const int K = uni((int)(a.g.row_ptr[cur + 1] - base));
             if (K == 0) break;  // dead end (:50-51)
             bool ok;
-            if (K <= kLdsSlots) ok = build_table(a, Tl, prev, base, K, lane);
-            else ok = build_table(a, Tg, prev, base, K, lane);
+            if (K <= kLdsSlots) ok = n2v::wave_build_table(a.g, Tl, prev, base, K, lane);
+            else ok = n2v::wave_build_table(a.g, Tg, prev, base, K, lane);
             if (!ok) { failed = true; break; }
             double u1, u2;
             const uint32_t t = (uint32_t)(len - 1);
@@ -208,7 +83,7 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
             else { qk = Tg[kk].q; Jk = Tg[kk].J; }
             const int pick = (u2 < qk) ? kk : Jk;  // :278-281
             prev = cur;
-            cur = uni(a.col[base + pick]);
+            cur = uni(a.g.col[base + pick]);
             if (lane == 0) out[len] = cur;
             __builtin_amdgcn_wave_barrier();  // the table is rebuilt in place on the next step
         }
@@ -251,7 +126,7 @@ extern "C" int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, c
         if (fit < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: scratch smaller than 4 x max_degree slots");
         if (blocks > fit) blocks = fit;
     }
-    OtfArgs a{row_ptr, col, w, p, q, symmetric, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
+    OtfArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
               rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, walks, lens, status};
     hipLaunchKernelGGL(walk_otf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return n2v::check_launch("n2v_walk_on_the_fly");
