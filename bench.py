@@ -276,8 +276,9 @@ def main():
     t_pre = time.perf_counter() - t0
     eng = g._engine
     if rank == 0:
-        log("[bench] %s: graph %.1fs, preprocess %.2fs (%d alias slots, %.1f GB)" % (
-            args.config, t_graph, t_pre, eng.total_slots, eng.total_slots * 16 / 1e9))
+        log("[bench] %s: graph %.1fs, preprocess %.2fs (%d alias slots, %.1f GB of %s slots)" % (
+            args.config, t_graph, t_pre, eng.total_slots, eng.total_slots * (32 if eng.edge_fat is not None else 16) / 1e9,
+            "fat 32-B" if eng.edge_fat is not None else "thin 16-B"))
 
     N = cg.n_nodes
     pos_begin, pos_end = sgns.shard_bounds(N, world, rank)
