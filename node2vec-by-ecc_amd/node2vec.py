@@ -396,7 +396,7 @@ class Graph():
             return torch.from_numpy(np.random.random_sample(n)).to(device)
         return _mt.global_uniforms_device(n, device)
 
-    def _resolve_stream_offsets(self, starts, n, num_walks, L, U, active):
+    def _resolve_stream_offsets(self, starts, n, num_walks, L, active):
         """Directed graph with reachable sinks: a walk that ends early consumes fewer uniforms, so the position
         of walk w in numpy's stream depends on the lengths of all walks before it (src/node2vec.py:76-77 stops
         without drawing).  The chain is resolved on the device window by window: the window's first walk has an
@@ -404,7 +404,8 @@ class Graph():
         of the new lengths every walk before the first one whose offset turned out different is final, and the
         next window starts there.  A pass costs one launch over at most 2^18 walks and one scalar read-back;
         a pass finalises 1 / P(a re-walked walk changes its length) walks on average (round 1 re-walked ALL
-        walks per pass)."""
+        walks per pass).  The uniforms are generated as the chain advances (a sliding piece of numpy's stream of
+        at least 2^24 doubles), not for all walks at once."""
         eng = self._engine
         d = eng.device
         W = n * num_walks
@@ -415,11 +416,20 @@ class Graph():
         starts_all = starts.repeat(num_walks)
         done, exact_off, window = 0, 0, 4096
         self.stream_passes = 0
+        U = torch.empty(0, dtype=torch.float64, device=d)     # stream positions [u_base, u_base + len(U))
+        u_base = 0
         while done < W:
             hi = min(W, done + window)
             g = guess[done:hi]
             off = (torch.cumsum(g, 0) - g + exact_off).contiguous()
-            w_win, l_win = self._walk(starts_all[done:hi].contiguous(), 1, L, rng="uniforms", uniforms=U, walk_uoff=off)
+            need_end = exact_off + int(g.sum().item()) + step + 2      # a re-walked walk may run to full length
+            if need_end > u_base + U.numel():
+                keep = U[exact_off - u_base:] if exact_off - u_base < U.numel() else U[:0]
+                have_end = max(u_base + U.numel(), exact_off)
+                U = torch.cat([keep, self._global_uniforms(max(need_end - have_end, 1 << 24), d)])
+                u_base = exact_off
+            w_win, l_win = self._walk(starts_all[done:hi].contiguous(), 1, L, rng="uniforms", uniforms=U,
+                                      walk_uoff=(off - u_base).contiguous())
             used = (l_win.to(torch.int64) - 1) * 2
             new_off = torch.cumsum(used, 0) - used + exact_off
             bad = new_off != off
@@ -471,8 +481,7 @@ class Graph():
                 it += k
             return walks, lens
         state = np.random.get_state()
-        U = self._global_uniforms(total_full, d)
-        walks, lens = self._resolve_stream_offsets(starts, n, num_walks, L, U, active)
+        walks, lens = self._resolve_stream_offsets(starts, n, num_walks, L, active)
         used = int(((lens.to(torch.int64) - 1) * 2).sum().item())
         np.random.set_state(state)
         _mt.advance_global_state(used)  # leave the global stream where the reference would
