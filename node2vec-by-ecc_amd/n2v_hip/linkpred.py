@@ -234,6 +234,8 @@ def link_prediction(vectors, graph, train_edges, test_edges, ks=KS, unseparated=
     known = np.isin(tr, labels).all(axis=1) if len(tr) else np.zeros(0, dtype=bool)
     da, db = graph.dense_of(tr[known, 0]), graph.dense_of(tr[known, 1])
     ok = (pos_r[da] >= 0) & (pos_c[db] >= 0)
+    if unseparated:
+        ok &= pos_r[da] < pos_c[db]          # only pairs nodes[i], nodes[j] with i < j are candidates (:72)
     keys = np.unique(pos_r[da[ok]] * n_cols + pos_c[db[ok]])
     total = n_rows * (n_rows - 1) // 2 if unseparated else n_rows * n_cols
     kmax = int(min(max(ks), max(total - len(keys), 0)))

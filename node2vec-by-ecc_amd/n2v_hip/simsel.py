@@ -104,7 +104,7 @@ def global_topk(A, B, k, method="cos", upper_triangle=False, exclude_keys=None, 
                 tau.fill_(float(keep.item()))
             n = scan(b, e)
         fold(n)
-        b, step = e, step * 2
+        b, step = e, min(step * 2, 1 << 21)      # one launch covers at most 65 535 row tiles
     s, r, c = best
     # descending score; ties in (row, col) order — a deterministic stand-in for the reference's set/argsort order
     key = r.to(torch.int64) * n_cols + c.to(torch.int64)
