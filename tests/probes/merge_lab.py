@@ -237,6 +237,14 @@ def main():
                     t = time.time()
                     extra = ""
                     NEG_HEAT[0] = 1.0
+                    if rule == "ship":                    # the product's constants for this replica count
+                        hb, sb = sgns.merge_constants(G)
+                        sy = max(1, int(np.ceil(tokens * (G - 1) / (sb * g.n_nodes))))
+                        m = simulate(G, corpus, g.n_nodes, rounds, sy, "hot:%g" % hb, 0)
+                        auc, _ = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
+                        print("[%s] G=%d budget=%g syncs=%d delay=0 rule=%-12s AUC %.5f  d=%+.5f  (%.1fs)"
+                              % (kind, G, sb, sy, "ship:%g" % hb, auc, auc - ref, time.time() - t), flush=True)
+                        continue
                     if rule.startswith("hotb:"):          # hotb:<budget>:<beta>: negatives count beta updates each
                         _, nb, beta = rule.split(":")
                         NEG_HEAT[0] = float(beta)

@@ -154,10 +154,14 @@ def _hub_partition(n=20000, k=100, m_in=200000, m_out=40000, seed=0):
 def setup(kind):
     if kind == "pp":
         return _auc_setup()
-    if kind == "hub":
+    if kind == "hub" or kind.startswith("hub:"):
         from n2v_hip import csr
         from oracle import sgns_oracle
-        edges = _hub_partition()
+        if kind == "hub":
+            edges = _hub_partition()
+        else:       # hub:<n>: the same generator scaled up (communities of ~200 nodes, 10 n + 2 n edges)
+            nn = int(kind.split(":")[1])
+            edges = _hub_partition(n=nn, k=nn // 200, m_in=10 * nn, m_out=2 * nn, seed=2)
         tr, te = sgns_oracle.split_edges(edges)
         g = csr.from_edges(tr[:, 0], tr[:, 1], None, False)
         print("hub graph: nodes %d train edges %d max degree %d" % (g.n_nodes, len(tr), g.degrees.max()), flush=True)
