@@ -218,6 +218,14 @@ def shard_bounds(n_items, world, rank):
 #     cadence an average row already has u ~ 500).  The delayed tier therefore exists (cold_delay=True, HOT_THETA)
 #     and is tested, but is OFF by default; what is hidden instead is the merge ARITHMETIC behind the wire time:
 #     the synchronous merge is pipelined over row ranges (ReplicaMerger.end_interval).
+#   * LIMIT OF THE SCHEME (lab9 / lab10 logs): the constants below were fitted on the two SMALL probe graphs.  On a
+#     131 072-node hub graph (10 walks of 80, 12-thread CPU comparator 0.88175, one GPU 0.88019) the same constants
+#     give -0.0019 (2 replicas), -0.0047 (4) and -0.0064 (8): at fixed tokens per row and interval the bias grows with
+#     the graph, every row being damped to about half of the summed change (w ~ 0.5 at u ~ 500) for the whole pass
+#     while the learning rate — and with it the saturation the damping is there for — decays to zero.  Making the
+#     budget grow with 1 / learning rate helps the large graph (-0.0034 / -0.0031 at 8 / 4 replicas) and hurts the
+#     small hub graph (-0.0061): no member of this family is inside the band at every size.  What is enforced by the
+#     tests is therefore the band on the two small graphs; C4-sized multi-GPU parity is an open item.
 # The arithmetic around the collectives is three fused kernels (csrc/n2v_merge.hip).
 HOT_BUDGET = 208.0
 HOT_THETA = 64.0

@@ -40,6 +40,14 @@ def rule_weights(rule, G, upd, alpha_now, r_opp, delay):
         return torch.ones_like(upd, dtype=torch.float32)
     if kind == "mean":
         return torch.full_like(upd, 1.0 / G, dtype=torch.float32)
+    if kind == "hota":
+        # the 'hot' weights with the budget growing as the learning rate decays: late in the pass the updates are
+        # small, every row is in the linear regime and the sum is exact — hota:<B>[:<power>]
+        b0, _, pw = arg.partition(":")
+        B = float(b0) * (0.025 / max(alpha_now, 1e-9)) ** float(pw or 1.0)
+        u = (G - 1) / G * upd
+        lam = torch.clamp(B / u.clamp_min(1e-30), max=1.0)
+        return (lam + (1 - lam) / G).float()
     if kind == "hot":
         B = float(arg or 256)
         u = (G - 1) / G * upd
