@@ -40,6 +40,8 @@ def rule_weights(rule, G, upd, alpha_now, r_opp, delay):
         return torch.ones_like(upd, dtype=torch.float32)
     if kind == "mean":
         return torch.full_like(upd, 1.0 / G, dtype=torch.float32)
+    if kind == "gs":      # one scalar weight on the summed change of EVERY row of both tables
+        return torch.full_like(upd, float(arg), dtype=torch.float32)
     if kind == "hota":
         # the 'hot' weights with the budget growing as the learning rate decays: late in the pass the updates are
         # small, every row is in the linear regime and the sum is exact — hota:<B>[:<power>]
@@ -161,7 +163,11 @@ def simulate(G, corpus, n_nodes, rounds, syncs, rule, delay=0, mode="atomic", bf
         alpha_now = 0.025 - (0.025 - 1e-4) * (c + 0.5) / syncs
         # mean squared norm of the OPPOSITE table's rows (what a row's updates are made of)
         r_sq = [float((base[1 - ti][live] ** 2).sum(1).mean()) for ti in range(2)]
-        wts = [rule_weights(rule, G, upd[ti], alpha_now, r_sq[ti], delay) for ti in range(2)]
+        if rule.startswith("hotsame:"):     # one lambda per WORD: both of its rows damped alike (by the syn0 count)
+            w_same = rule_weights("hot:" + rule.split(":")[1], G, upd[0], alpha_now, 0.0, delay)
+            wts = [w_same, w_same]
+        else:
+            wts = [rule_weights(rule, G, upd[ti], alpha_now, r_sq[ti], delay) for ti in range(2)]
         if delay == 0:
             for ti, nm in enumerate(names):
                 S = torch.zeros_like(base[ti])
