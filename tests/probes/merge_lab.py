@@ -134,6 +134,68 @@ def simulate_hybrid(G, corpus, n_nodes, rounds, syncs, rule, theta, mode="atomic
     return models[0], frac
 
 
+def simulate_tiers_sum(G, corpus, n_nodes, rounds, syncs, theta, n_tiers=4, ratio=4, mode="atomic", bf16=True):
+    """PURE SUMS at per-row cadences.  Base cadence `syncs` merges per pass for every row; a row whose expected updates
+    by the other replicas per base interval exceed theta * ratio^(j-1) is in tier j >= 1 and merged ratio^j times per
+    base interval (hubs, frequent negatives: small messages, often).  No damping anywhere: every change is applied
+    exactly once at weight 1, only the time at which the other replicas see it differs."""
+    n = corpus.walks.shape[0] // rounds
+    dev = corpus.walks.device
+    models = [sgns.SgnsModel(n_nodes, dim=128, window=WINDOW, negative=NEG, seed=1, update_mode=mode) for _ in range(G)]
+    counts = torch.bincount(corpus.walks.reshape(-1).long(), minlength=n_nodes)
+    for m in models:
+        m.build_vocab(counts=counts)
+    shards = []
+    for r in range(G):
+        b, e = sgns.shard_bounds(n, G, r)
+        idx = (torch.arange(rounds, device=dev)[:, None] * n + torch.arange(b, e, device=dev)[None, :]).reshape(-1)
+        shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
+    n_global = corpus.walks.shape[0]
+    names = ("syn0", "syn1neg")
+    base = [getattr(models[0], nm).clone() for nm in names]
+    upd = expected_updates(counts, n_global * float(L) / syncs)
+    tiers = []
+    for ti in range(2):
+        u = (G - 1) / G * upd[ti]
+        t = torch.clamp(torch.ceil(torch.log(u.clamp_min(1e-30) / theta) / np.log(ratio)) + 1, 0, n_tiers - 1).long()
+        t = torch.where(u > theta, t.clamp_min(1), torch.zeros_like(t))
+        tiers.append(t)
+    sub = ratio ** (n_tiers - 1)
+    rows_of = [[torch.nonzero(tiers[ti] >= j).flatten() for j in range(n_tiers)] for ti in range(2)]   # tier >= j merge together
+    total_sub = syncs * sub
+    msg_rows = 0
+    for c in range(total_sub):
+        for r, m in enumerate(models):
+            w, l, off = shards[r]
+            b, e = sgns.shard_bounds(w.shape[0], total_sub, c)
+            if e > b:
+                m.train_pass(w[b:e], l[b:e], sentences_base=b * G, sentences_step=G, sentences_total=n_global,
+                             walk_id_base=off + b)
+        # the coarsest tier level that is due now: tier j is due every sub / ratio^j sub-intervals
+        due = None
+        for j in range(n_tiers):
+            if (c + 1) % (sub // ratio ** j) == 0:
+                due = j
+                break
+        if due is None:
+            continue
+        for ti, nm in enumerate(names):
+            rows = rows_of[ti][due]
+            if rows.numel() == 0:
+                continue
+            msg_rows += int(rows.numel())
+            S = torch.zeros((rows.numel(), base[ti].shape[1]), device=dev)
+            for m in models:
+                d = getattr(m, nm)[rows] - base[ti][rows]
+                S += d.bfloat16().float() if bf16 else d
+            new = base[ti][rows] + S
+            base[ti][rows] = new
+            for m in models:
+                getattr(m, nm)[rows] = new
+    frac = [[float((tiers[ti] == j).float().mean()) for j in range(n_tiers)] for ti in range(2)]
+    return models[0], frac, msg_rows / (2.0 * n_nodes * syncs)
+
+
 def simulate(G, corpus, n_nodes, rounds, syncs, rule, delay=0, mode="atomic", bf16=True):
     n = corpus.walks.shape[0] // rounds
     dev = corpus.walks.device
@@ -251,6 +313,14 @@ def main():
                     t = time.time()
                     extra = ""
                     NEG_HEAT[0] = 1.0
+                    if rule.startswith("tsum:"):          # tsum:<theta>[:<tiers>]: pure sums at per-row cadences
+                        _, th, *rest = rule.split(":")
+                        m, frac, vol = simulate_tiers_sum(G, corpus, g.n_nodes, rounds, syncs, float(th), int(rest[0]) if rest else 4)
+                        auc, _ = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
+                        print("[%s] G=%d budget=%g syncs=%d delay=0 rule=%-12s AUC %.5f  d=%+.5f  (%.1fs) tiers syn0 %s syn1neg %s rows/merge x%.2f"
+                              % (kind, G, budget, syncs, rule, auc, auc - ref, time.time() - t,
+                                 ["%.3f" % x for x in frac[0]], ["%.3f" % x for x in frac[1]], vol), flush=True)
+                        continue
                     if rule == "ship":                    # the product's constants for this replica count
                         hb, sb = sgns.merge_constants(G)
                         sy = max(1, int(np.ceil(tokens * (G - 1) / (sb * g.n_nodes))))
