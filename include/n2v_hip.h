@@ -267,6 +267,11 @@ int n2v_merge_hot_apply(float* x, float* xs, float* base, int32_t stride, const 
                         void* stream);
 int n2v_merge_flush(float* x, float* xs, float* base, int64_t n_rows, int32_t stride, const float* w,
                     const int32_t* hot_pos, const void* cold_sum_last, int32_t wire_bf16, void* stream);
+/* Tiered pure-sum merges (merge="tsum"): rows are merged at per-row cadences, always by the plain sum of the replicas'
+ * changes.  n2v_merge_pack_rows: wire[j] = x[rows[j]] - base[rows[j]] for a row LIST (int64, the rows of the tiers that
+ * are due); after the all-reduce n2v_merge_hot_apply (w == 1, xs == x) folds the sum into base and resets x.       */
+int n2v_merge_pack_rows(const float* x, const float* base, int32_t stride, const int64_t* rows, int64_t n_list,
+                        void* wire, int32_t wire_bf16, void* stream);
 
 #ifdef __cplusplus
 }

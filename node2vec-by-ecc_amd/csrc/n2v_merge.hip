@@ -88,6 +88,18 @@ merge_flush_kernel(float* __restrict__ x, float* __restrict__ xs, float* __restr
     }
 }
 
+// wire[j] = x[rows[j]] - base[rows[j]]: the change of a row LIST since its last merge (tiered pure-sum merges)
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+merge_pack_rows_kernel(const float* __restrict__ x, const float* __restrict__ base, int stride, const int64_t* __restrict__ rows,
+                       int64_t n_list, void* __restrict__ wire) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (j >= n_list) return;
+    const int64_t o = rows[j] * stride;
+    for (int c = lane; c < stride; c += 64) wire_store<BF16>(wire, j * stride + c, x[o + c] - base[o + c]);
+}
+
 int rows_grid(int64_t n, unsigned* blocks) {
     const int64_t b = (n + 3) / 4;
     if (b > 0x7fffffff) return -1;
@@ -141,4 +153,18 @@ extern "C" int n2v_merge_flush(float* x, float* xs, float* base, int64_t n_rows,
     else hipLaunchKernelGGL((merge_flush_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, base, n_rows,
                             (int)stride, w, hot_pos, cold_sum_last);
     return n2v::check_launch("n2v_merge_flush");
+}
+
+extern "C" int n2v_merge_pack_rows(const float* x, const float* base, int32_t stride, const int64_t* rows, int64_t n_list,
+                                   void* wire, int32_t wire_bf16, void* stream) {
+    if (n_list < 0 || stride < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_pack_rows: bad sizes");
+    if (n_list == 0) return N2V_OK;
+    if (!x || !base || !rows || !wire) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_pack_rows: null pointer");
+    unsigned blocks;
+    if (rows_grid(n_list, &blocks)) return n2v::fail(N2V_ERR_INVALID, "n2v_merge_pack_rows: too many rows");
+    if (wire_bf16) hipLaunchKernelGGL((merge_pack_rows_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, base,
+                                      (int)stride, rows, n_list, wire);
+    else hipLaunchKernelGGL((merge_pack_rows_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, base, (int)stride,
+                            rows, n_list, wire);
+    return n2v::check_launch("n2v_merge_pack_rows");
 }

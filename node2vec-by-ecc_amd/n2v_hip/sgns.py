@@ -331,6 +331,13 @@ class HipMergeOps:
                 _lib.ptr(x), _lib.ptr(xs), _lib.ptr(base), int(x.shape[1]), _lib.ptr(w), _lib.ptr(hot_rows),
                 int(hot_rows.numel()), _lib.ptr(hot_sum), self._bf16(hot_sum), _lib.stream_ptr(x.device)))
 
+    def pack_rows(self, x, base, rows, wire):
+        self._check(x)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.n2v_merge_pack_rows(
+                _lib.ptr(x), _lib.ptr(base), int(x.shape[1]), _lib.ptr(rows), int(rows.numel()), _lib.ptr(wire),
+                self._bf16(wire), _lib.stream_ptr(x.device)))
+
     def flush(self, x, xs, base, w, hot_pos, sum_last):
         self._check(x)
         with torch.cuda.device(x.device):
@@ -507,6 +514,85 @@ class ReplicaMerger:
             self.flush()
 
 
+# ---- tiered pure-sum merges (merge="tsum"): the scheme that meets the AUC band at every graph size in simulation
+TSUM_STALENESS_BUDGET = 24.0   # base cadence: every row is merged once per this many tokens per row from the others
+TSUM_THETA = 500.0             # expected updates by the other replicas between two merges of a row, at most
+TSUM_TIERS = 4                 # tier j is merged TSUM_RATIO^j times per base interval (1, 4, 16, 64)
+TSUM_RATIO = 4
+
+
+class SumTierPlan:
+    """Per-row merge cadences for pure sums: a row whose expected updates by the other replicas per BASE interval
+    lie in (theta * ratio^(j-1), theta * ratio^j] is in tier j and merged ratio^j times per base interval, so that no
+    row collects more than ~theta foreign updates between two of its merges (rows beyond the last tier: as often as
+    that tier).  Identical on every rank."""
+
+    def __init__(self, counts, interval_tokens_global, world, window, negative, device, theta=TSUM_THETA,
+                 n_tiers=TSUM_TIERS, ratio=TSUM_RATIO):
+        self.n_tiers, self.ratio, self.world = int(n_tiers), int(ratio), world
+        self.sub = self.ratio ** (self.n_tiers - 1)          # sub-intervals per base interval
+        self.tier, self.rows_ge = [], []
+        for upd in expected_updates(counts, interval_tokens_global, window, negative, device):
+            u = (world - 1) / world * upd
+            t = torch.ceil(torch.log(u.clamp_min(1e-30) / theta) / np.log(self.ratio)).clamp(0, self.n_tiers - 1).long()
+            t = torch.where(u > theta, t.clamp_min(1), torch.zeros_like(t))
+            self.tier.append(t)
+            n = int(u.numel())
+            self.rows_ge.append([torch.arange(n, dtype=torch.int64, device=device)] +
+                                [torch.nonzero(t >= j).flatten().contiguous() for j in range(1, self.n_tiers)])
+
+    def level_due(self, sub_index):
+        """The coarsest tier level whose merge is due after sub-interval `sub_index` (0-based, global), or None:
+        level j is due every sub / ratio^j sub-intervals; a merge of level j covers every tier >= j."""
+        for j in range(self.n_tiers):
+            if (sub_index + 1) % (self.sub // self.ratio ** j) == 0:
+                return j
+        return None
+
+
+class TieredSumMerger:
+    """One rank's side of the tiered pure-sum merges of `tables`: merge(level) packs the changes of the rows of
+    tiers >= level since THEIR last merge, all-reduces them (sum) and folds the sum in — every change is applied exactly
+    once with weight 1 on every rank; only the time at which the other ranks see it depends on the row's tier."""
+
+    def __init__(self, tables, plan, comm, ops=None):
+        self.t, self.plan, self.comm = list(tables), plan, comm
+        self.ops = ops if ops is not None else HipMergeOps()
+        dev = self.t[0].device
+        wire = getattr(comm, "wire_dtype", None) or torch.float32
+        self.base = [t.clone() for t in self.t]
+        stride = int(self.t[0].shape[1])
+        self.ones = [torch.ones(int(t.shape[0]), dtype=torch.float32, device=dev) for t in self.t]
+        self.wire = [torch.zeros((int(t.shape[0]), stride), dtype=wire, device=dev) for t in self.t]
+        self.n_merges = [0] * plan.n_tiers
+
+    def pack(self, level):
+        """-> the wire views holding this rank's changes of the rows of tiers >= level (one per table, may be empty)."""
+        views = []
+        for i, t in enumerate(self.t):
+            rows = self.plan.rows_ge[i][level]
+            v = self.wire[i][: int(rows.numel())]
+            if rows.numel():
+                self.ops.pack_rows(t, self.base[i], rows, v)
+            views.append(v)
+        return views
+
+    def apply(self, level, views):
+        for i, t in enumerate(self.t):
+            rows = self.plan.rows_ge[i][level]
+            if rows.numel():
+                self.ops.hot_apply(t, t, self.base[i], self.ones[i], rows, views[i])
+        self.n_merges[level] += 1
+
+    def merge(self, level):
+        views = self.pack(level)
+        handles = [self.comm.all_reduce_async(v) if v.numel() else None for v in views]
+        for h in handles:
+            if h is not None:
+                h.wait()
+        self.apply(level, views)
+
+
 def auto_syncs(tokens_global, n_words, world):
     """Merges per pass so that (world-1) * tokens per row per interval <= the staleness budget of merge_constants."""
     if world <= 1:
@@ -535,11 +621,42 @@ def _merge_setup(model, L, n_walks_global, world, syncs_per_epoch, merge, cold_d
     return n_chunks, plan
 
 
+def _tsum_setup(model, L, n_walks_global, world, syncs_per_epoch):
+    n_chunks = (max(1, int(np.ceil(n_walks_global * L * (world - 1) / (TSUM_STALENESS_BUDGET * max(model.n_words, 1)))))
+                if syncs_per_epoch == "auto" else int(syncs_per_epoch))
+    n_chunks = max(1, min(n_chunks, max(1, n_walks_global // world)))
+    plan = SumTierPlan(model.counts, n_walks_global * L / n_chunks, world, model.window, model.negative, model.device)
+    return n_chunks, plan
+
+
+def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops):
+    """merge="tsum": pure sums at per-row cadences (SumTierPlan).  The pass is cut into base intervals x sub-intervals;
+    after every sub-interval the tiers that are due are merged.  Meets the AUC band at every graph size in simulation
+    (DESIGN.md 6), but the launches between two hub-tier merges are short (n_local / (n_chunks * 64) walks): the
+    price of synchronous hub tiers with one wavefront per walk."""
+    n_local = int(walks.shape[0])
+    world = comm.world
+    total = epochs * n_walks_global
+    n_chunks, plan = _tsum_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch)
+    merger = TieredSumMerger([model.syn0, model.syn1neg], plan, comm, ops=ops)
+    subs = chunk_plan(n_local, n_chunks * plan.sub, exact=True)
+    for ep in range(epochs):
+        for c, (b, e) in enumerate(subs):
+            if e > b:
+                model.train_pass(walks[b:e], None if lens is None else lens[b:e],
+                                 sentences_base=ep * n_walks_global + b * world, sentences_step=world,
+                                 sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b)
+            level = plan.level_due(c)
+            if level is not None:
+                merger.merge(level)
+    return merger
+
+
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
           merge="hot", overlap=True, cold_delay=False, ops=None):
     """Train `epochs` passes over this rank's walks.  With a communicator the replicas are merged
-    `syncs_per_epoch` times per pass ("auto": auto_syncs) by a ReplicaMerger; returns the merger (None on one
-    GPU) so that the caller can read its timers."""
+    `syncs_per_epoch` times per pass ("auto": auto_syncs) by a ReplicaMerger — or, merge="tsum", by pure sums at
+    per-row cadences (TieredSumMerger); returns the merger (None on one GPU) so that the caller can read its timers."""
     n_local = int(walks.shape[0])
     if n_walks_global is None:
         n_walks_global = n_local
@@ -550,6 +667,8 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
             model.train_pass(walks, lens, sentences_base=ep * n_walks_global, sentences_step=1,
                              sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset)
         return None
+    if merge == "tsum":
+        return _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops)
     n_chunks, plan = _merge_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch, merge, cold_delay)
     merger = ReplicaMerger([model.syn0, model.syn1neg], plan, comm, overlap=overlap, ops=ops)
     chunks = chunk_plan(n_local, n_chunks, exact=True)
@@ -606,6 +725,30 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
     on a one-GPU box.  Returns the number of merges per pass."""
     G = len(models)
     L = int(shards[0][0].shape[1])
+    if merge == "tsum":
+        n_chunks, plan = _tsum_setup(models[0], L, n_walks_global, G, syncs_per_epoch)
+        group = _SimGroup(G, wire_dtype)
+        mergers = [TieredSumMerger([m.syn0, m.syn1neg], plan, group.comm()) for m in models]
+        subs = [chunk_plan(int(w.shape[0]), n_chunks * plan.sub, exact=True) for w, _, _ in shards]
+        total = epochs * n_walks_global
+        for ep in range(epochs):
+            for c in range(n_chunks * plan.sub):
+                for r, m in enumerate(models):
+                    w, l, off = shards[r]
+                    b, e = subs[r][c]
+                    if e > b:
+                        m.train_pass(w[b:e], None if l is None else l[b:e], sentences_base=ep * n_walks_global + b * G,
+                                     sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b)
+                level = plan.level_due(c)
+                if level is None:
+                    continue
+                views = [mg.pack(level) for mg in mergers]
+                for i in range(2):
+                    if views[0][i].numel():
+                        _SimGroup.reduce([v[i] for v in views])
+                for mg, v in zip(mergers, views):
+                    mg.apply(level, v)
+        return n_chunks
     n_chunks, plan = _merge_setup(models[0], L, n_walks_global, G, syncs_per_epoch, merge, cold_delay)
     group = _SimGroup(G, wire_dtype)
     mergers = [ReplicaMerger([m.syn0, m.syn1neg], plan, group.comm()) for m in models]

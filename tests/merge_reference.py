@@ -28,6 +28,9 @@ class TorchMergeOps:
             x[cold] = nx
             xs[cold] = nx
 
+    def pack_rows(self, x, base, rows, wire):
+        wire[: rows.numel()] = (x[rows] - base[rows]).to(wire.dtype)
+
     def hot_apply(self, x, xs, base, w, hot_rows, hot_sum):
         b = base[hot_rows] + w[hot_rows, None] * hot_sum.float()
         base[hot_rows] = b

@@ -312,6 +312,32 @@ def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, kind, G):
     assert abs(auc - auc_cpu) <= AUC_BAND, (kind, G, n_syncs, auc, auc_cpu)
 
 
+@pytest.mark.parametrize("kind,G", [("uniform", 2), ("uniform", 8), ("hub", 8)])
+def test_tiered_sum_merges_auc_within_band_simulated(torch_cuda, kind, G):
+    """merge="tsum" — pure sums at per-row cadences (every row 234 times per pass at 8 replicas, hub rows 4 / 16 / 64
+    times as often), no damping, no fitted weights: inside the band on both graphs.  (On a 131 072-node hub graph the
+    same scheme is at -0.0002 where the damped default is at -0.0064: profiles/r02/logs/lab15_hub131k.log.)"""
+    torch = torch_cuda
+    from n2v_hip import linkpred, sgns
+    g, corpus, counts, te_d, neg_d, rounds, auc_cpu = _band_case(kind)
+    n = g.n_nodes
+    models, shards = [], []
+    for r in range(G):
+        m = sgns.SgnsModel(n, dim=128, window=10, negative=5, seed=1)
+        m.build_vocab(counts=counts)
+        models.append(m)
+        b, e = sgns.shard_bounds(n, G, r)
+        idx = (torch.arange(rounds, device="cuda")[:, None] * n + torch.arange(b, e, device="cuda")[None, :]).reshape(-1)
+        shards.append((corpus.walks[idx].contiguous(), corpus.lens[idx].contiguous(), b * rounds))
+    n_syncs = sgns.train_simulated_replicas(models, shards, n_walks_global=corpus.walks.shape[0], merge="tsum")
+    torch.cuda.synchronize()
+    for m in models[1:]:
+        assert torch.equal(m.syn0, models[0].syn0) and torch.equal(m.syn1neg, models[0].syn1neg)
+    auc, _ = linkpred.get_roc_score(models[0].vectors(), te_d, neg_d)
+    print("tsum %s G=%d base syncs=%d: AUC %.5f vs sequential CPU %.5f (%+.5f)" % (kind, G, n_syncs, auc, auc_cpu, auc - auc_cpu))
+    assert abs(auc - auc_cpu) <= AUC_BAND, (kind, G, n_syncs, auc, auc_cpu)
+
+
 def test_merge_kernels_equal_torch_restatement(torch_cuda):
     """n2v_merge_snapshot / _hot_apply / _flush (csrc/n2v_merge.hip) against tests/merge_reference.py, bit for bit,
     with float32 and bfloat16 wires, with and without a hot tier and a pending cold sum."""
@@ -345,6 +371,13 @@ def test_merge_kernels_equal_torch_restatement(torch_cuda):
                 assert len(outs[0]) == len(outs[1])
                 for a_, b_ in zip(*outs):
                     assert torch.equal(a_, b_), (wire, n_hot, sum_prev is None)
+            if n_hot:       # the row-list pack of the tiered pure-sum merges
+                packs = []
+                for ops in (hip, ref):
+                    wbuf = torch.zeros((n, stride), device="cuda").to(wire)
+                    ops.pack_rows(state[0], state[2], hot_rows, wbuf[:n_hot])
+                    packs.append(wbuf)
+                assert torch.equal(packs[0], packs[1])
 
 
 def test_main_link_flow_end_to_end(torch_cuda):

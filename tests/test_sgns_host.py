@@ -141,6 +141,70 @@ def test_merger_protocol_is_linear_in_the_changes():
             assert all(torch.equal(mg.base[0], tabs[0]) and torch.equal(mg.xs[0], tabs[0]) for mg in mergers)
 
 
+def test_sum_tier_plan_and_schedule():
+    """merge="tsum": tier j rows are merged ratio^j times per base interval so that no row collects more than theta
+    foreign updates between two of its merges."""
+    from n2v_hip import sgns
+    counts = np.full(1000, 100, dtype=np.int64)
+    counts[:3] = 3000          # 30 x the average
+    counts[3] = 60000          # 600 x: beyond the last tier
+    T = counts.sum() * 0.2     # tokens per base interval
+    plan = sgns.SumTierPlan(counts, T, 8, 10, 5, torch.device("cpu"), theta=500.0, n_tiers=4, ratio=4)
+    (u0, u1) = [(7 / 8) * x for x in sgns.expected_updates(counts, T, 10, 5, torch.device("cpu"))]
+    assert plan.sub == 64
+    for ti, u in enumerate((u0, u1)):
+        t = plan.tier[ti]
+        assert bool((t[u <= 500] == 0).all())
+        for j in (1, 2):
+            sel = (u > 500 * 4 ** (j - 1)) & (u <= 500 * 4 ** j)
+            assert bool((t[sel] == j).all())
+        assert bool((t[u > 500 * 16] == 3).all())
+        # between two merges of a row (except beyond the last tier): at most theta foreign updates
+        per_merge = u / (4.0 ** t.double())
+        assert bool((per_merge[u <= 500 * 64] <= 500 + 1e-9).all())
+        assert plan.rows_ge[ti][0].numel() == 1000 and plan.rows_ge[ti][3].tolist() == torch.nonzero(t >= 3).flatten().tolist()
+    due = [plan.level_due(c) for c in range(128)]
+    assert due[63] == 0 and due[127] == 0 and due[15] == 1 and due[31] == 1 and due[3] == 2 and due[0] == 3
+    assert sum(1 for d in due[:64] if d is not None and d <= 1) == 4 and all(d is not None for d in due)   # ratio^(tiers-1) levels: every sub-interval merges the last tier
+
+
+def test_tiered_sum_merger_applies_every_change_once():
+    """Pure sums at per-row cadences: whatever the tiers, after the pass every replica holds
+    base0 + (sum of all changes of all replicas), and the replicas agree after every level-0 merge."""
+    from merge_reference import TorchMergeOps
+    from n2v_hip import sgns
+    G, n, stride = 3, 9, 4
+    g = torch.Generator().manual_seed(2)
+    base0 = torch.randn(n, stride, generator=g)
+    plan = sgns.SumTierPlan.__new__(sgns.SumTierPlan)
+    plan.n_tiers, plan.ratio, plan.sub, plan.world = 3, 2, 4, G
+    tier = torch.tensor([0, 0, 1, 2, 0, 1, 0, 2, 0])
+    plan.tier = [tier]
+    plan.rows_ge = [[torch.arange(n)] + [torch.nonzero(tier >= j).flatten() for j in (1, 2)]]
+    n_sub = 12                                   # 3 base intervals x 4 sub-intervals
+    incr = torch.randn(n_sub, G, n, stride, generator=g) * 0.1
+    for wire in (None, torch.bfloat16):
+        group = sgns._SimGroup(G, wire)
+        tabs = [base0.clone() for _ in range(G)]
+        mergers = [sgns.TieredSumMerger([t], plan, group.comm(), ops=TorchMergeOps()) for t in tabs]
+        for c in range(n_sub):
+            for r in range(G):
+                tabs[r] += incr[c, r]
+            level = plan.level_due(c)
+            assert level is not None
+            views = [mg.pack(level) for mg in mergers]
+            sgns._SimGroup.reduce([v[0] for v in views])
+            for mg, v in zip(mergers, views):
+                mg.apply(level, v)
+            hot = plan.rows_ge[0][level]
+            for t in tabs[1:]:
+                assert torch.equal(t[hot], tabs[0][hot])          # merged rows agree on every replica
+            if level == 0:
+                want = base0 + incr[: c + 1].sum(dim=(0, 1))
+                assert torch.allclose(tabs[0], want, atol=1e-5 if wire is None else 3e-2)
+        assert mergers[0].n_merges == [3, 3, 6]
+
+
 def test_cold_rows_keep_the_own_change_until_it_is_merged():
     """After an interval a replica's cold rows hold base + its OWN change (the other replicas' changes arrive one
     interval later); its hot rows are merged at once."""
@@ -220,6 +284,20 @@ for overlap in (True, False):
     assert mg.n_merges == K
     results.append(t.clone())
 assert torch.equal(results[0], results[1])     # the same bits with the cold all-reduce overlapped or waited for
+# tiered pure sums over the same process group
+tp = sgns.SumTierPlan.__new__(sgns.SumTierPlan)
+tp.n_tiers, tp.ratio, tp.sub, tp.world = 2, 2, 2, 2
+tier = torch.tensor([0, 1, 0, 1, 0, 0])
+tp.tier = [tier]
+tp.rows_ge = [[torch.arange(n), torch.nonzero(tier >= 1).flatten()]]
+t = base0.clone()
+mg = sgns.TieredSumMerger([t], tp, comm, ops=TorchMergeOps())
+for k in range(K):
+    t += incr[k, rank]
+    mg.merge(tp.level_due(k))
+assert torch.allclose(t, base0 + incr.sum(dim=(0, 1)), atol=1e-5)
+other = t.clone(); dist.broadcast(other, src=0)
+assert torch.equal(other, t) and mg.n_merges == [K // 2, K // 2]
 b, e = sgns.shard_bounds(101, 2, rank)
 tot = torch.tensor([e - b]); dist.all_reduce(tot); assert int(tot) == 101
 dist.destroy_process_group()
