@@ -227,7 +227,7 @@ def shard_bounds(n_items, world, rank):
 #     small hub graph (-0.0061): no member of this family is inside the band at every size.  What is enforced by the
 #     tests is therefore the band on the two small graphs; C4-sized multi-GPU parity is an open item.
 #   * What does reach the comparator at every size in simulation: PURE SUMS at per-row cadences (lab13-15) — every row
-#     merged 234 times per pass, rows with more than 500 expected updates by the others per base interval 16 / 64
+#     merged 234 times per pass, rows with more than 125 expected updates by the others per base interval 4 / 16 / 64
 #     times as often: hub graph +0.0002, uniform -0.0005, 131k-node hub graph -0.0002 at 8 replicas.  Not shipped:
 #     with one wavefront per walk the launches between two hub-tier merges would cover ~100 walks at C4's size.
 # The arithmetic around the collectives is three fused kernels (csrc/n2v_merge.hip).
@@ -516,7 +516,8 @@ class ReplicaMerger:
 
 # ---- tiered pure-sum merges (merge="tsum"): the scheme that meets the AUC band at every graph size in simulation
 TSUM_STALENESS_BUDGET = 24.0   # base cadence: every row is merged once per this many tokens per row from the others
-TSUM_THETA = 500.0             # expected updates by the other replicas between two merges of a row, at most
+TSUM_THETA = 125.0             # expected updates by the other replicas between two merges of a row, at most
+                               # (tests/probes/tsum_probe.py: 8 replicas, hub graph -0.0005 at 125, -0.0029 at 500)
 TSUM_TIERS = 4                 # tier j is merged TSUM_RATIO^j times per base interval (1, 4, 16, 64)
 TSUM_RATIO = 4
 
@@ -607,7 +608,9 @@ def chunk_plan(n_local, n_chunks, exact=False):
     n_chunks = max(1, int(n_chunks))
     if not exact:
         n_chunks = min(n_chunks, max(n_local, 1))
-    return [shard_bounds(n_local, n_chunks, c) for c in range(n_chunks)]
+    # evenly spread (interval c = [c*n/k, (c+1)*n/k)): with more intervals than sentences the sentences must not all
+    # sit in the first intervals, or the merges after them would have nothing left to merge
+    return [(c * n_local // n_chunks, (c + 1) * n_local // n_chunks) for c in range(n_chunks)]
 
 
 def _merge_setup(model, L, n_walks_global, world, syncs_per_epoch, merge, cold_delay):

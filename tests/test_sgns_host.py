@@ -55,6 +55,10 @@ def test_auto_syncs_and_chunk_plan():
     # exact: the same number of intervals on every rank, empty ones included, covering the shard exactly once
     p5 = chunk_plan(5, 8, exact=True)
     assert len(p5) == 8 and sum(e - b for b, e in p5) == 5 and p5[-1][1] == 5 and len(chunk_plan(0, 3, exact=True)) == 3
+    # more intervals than sentences: spread over the whole pass, not packed into the first intervals
+    p = chunk_plan(100, 1000, exact=True)
+    filled = [i for i, (b, e) in enumerate(p) if e > b]
+    assert len(filled) == 100 and max(e - b for b, e in p) == 1 and filled[-1] >= 990 and filled[50] in range(495, 515)
 
 
 def test_merge_weights_limits():
@@ -149,7 +153,7 @@ def test_sum_tier_plan_and_schedule():
     counts[:3] = 3000          # 30 x the average
     counts[3] = 60000          # 600 x: beyond the last tier
     T = counts.sum() * 0.2     # tokens per base interval
-    plan = sgns.SumTierPlan(counts, T, 8, 10, 5, torch.device("cpu"), theta=500.0, n_tiers=4, ratio=4)
+    plan = sgns.SumTierPlan(counts, T, 8, 10, 5, torch.device("cpu"), theta=500.0, n_tiers=4, ratio=4)   # explicit theta
     (u0, u1) = [(7 / 8) * x for x in sgns.expected_updates(counts, T, 10, 5, torch.device("cpu"))]
     assert plan.sub == 64
     for ti, u in enumerate((u0, u1)):
