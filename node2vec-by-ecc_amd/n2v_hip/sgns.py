@@ -226,10 +226,11 @@ def shard_bounds(n_items, world, rank):
 #     budget grow with 1 / learning rate helps the large graph (-0.0034 / -0.0031 at 8 / 4 replicas) and hurts the
 #     small hub graph (-0.0061): no member of this family is inside the band at every size.  What is enforced by the
 #     tests is therefore the band on the two small graphs; C4-sized multi-GPU parity is an open item.
-#   * What does reach the comparator at every size in simulation: PURE SUMS at per-row cadences (lab13-15) — every row
-#     merged 234 times per pass, rows with more than 125 expected updates by the others per base interval 4 / 16 / 64
-#     times as often: hub graph +0.0002, uniform -0.0005, 131k-node hub graph -0.0002 at 8 replicas.  Not shipped:
-#     with one wavefront per walk the launches between two hub-tier merges would cover ~100 walks at C4's size.
+#   * What does reach the comparator at every size in simulation: PURE SUMS at per-row cadences (merge="tsum" below;
+#     lab13-15) — every row merged 234 times per pass, rows with more than 125 expected updates by the others per base
+#     interval 4 / 16 / 64 times as often: product path, 8 replicas: hub graph -0.0001, uniform -0.0000; lab, 131k-node
+#     hub graph -0.0002.  An option, not the default: with one wavefront per walk the launches between two hub-tier
+#     merges cover ~100 walks at C4's size (2.4e7 pairs/s per GPU, tools/sgns_launch_probe.py).
 # The arithmetic around the collectives is three fused kernels (csrc/n2v_merge.hip).
 HOT_BUDGET = 208.0
 HOT_THETA = 64.0
