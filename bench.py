@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = BASELINE config C4 (the SAME rounds x N_nodes walks, start positions split "
                          "over the ranks, src/main_link.py:261-264); weak = every rank walks rounds x N_nodes")
+    ap.add_argument("--merge", default="hot", choices=["hot", "tsum", "delta", "avg"],
+                    help="N > 1: replica merges — 'hot' (per-row weights, few merges: the throughput default) or 'tsum' (pure "
+                         "sums at per-row cadences: meets the AUC band at every size in simulation, short launches)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for the cold rows' all-reduce at once instead of under the next interval (A/B)")
     ap.add_argument("--update-mode", default="auto", choices=["auto", "atomic", "agent", "plain"],
@@ -308,8 +311,9 @@ def main():
 
     def sgns_step(step_no, timed=False):
         mg = sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
-                        syncs_per_epoch=syncs, overlap=not args.no_overlap)
-        if timed and mg is not None:
+                        syncs_per_epoch=syncs if args.merge != "tsum" else "auto", merge=args.merge,
+                        overlap=not args.no_overlap)
+        if timed and isinstance(mg, sgns.ReplicaMerger):
             if mergers:
                 mergers[-1].release()       # keep the timers, not 2.5 GB of snapshots per timed step
             mergers.append(mg)
@@ -440,8 +444,9 @@ def main():
         "config": {"workload": desc, "walk_length": L, "rounds_per_step": rounds_total,
                    "walks_per_step_global": n_global, "window": window, "negative": negative, "dim": args.dim,
                    "rng": "philox4x32-10 in-kernel (walk rule bit-identical to the reference under given uniforms)",
-                   "sharding": "start-vertex shards, %d 'hot'-weighted merges per SGNS pass (hot rows synchronously, cold "
-                               "rows' all-reduce under the next interval; RCCL, bf16 wire)" % syncs
+                   "sharding": ("start-vertex shards, %d 'hot'-weighted synchronous merges per SGNS pass, pipelined over row "
+                                "ranges (RCCL, bf16 wire)" % syncs) if args.merge == "hot" else
+                               "start-vertex shards, merge=%s" % args.merge
                    if world > 1 else "single GPU", **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
                  "row_sharing": model.update_mode_name,
