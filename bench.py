@@ -444,10 +444,10 @@ def main():
         "config": {"workload": desc, "walk_length": L, "rounds_per_step": rounds_total,
                    "walks_per_step_global": n_global, "window": window, "negative": negative, "dim": args.dim,
                    "rng": "philox4x32-10 in-kernel (walk rule bit-identical to the reference under given uniforms)",
-                   "sharding": ("start-vertex shards, %d 'hot'-weighted synchronous merges per SGNS pass, pipelined over row "
-                                "ranges (RCCL, bf16 wire)" % syncs) if args.merge == "hot" else
-                               "start-vertex shards, merge=%s" % args.merge
-                   if world > 1 else "single GPU", **info},
+                   "sharding": "single GPU" if world == 1 else (
+                       ("start-vertex shards, %d 'hot'-weighted synchronous merges per SGNS pass, pipelined over row "
+                        "ranges (RCCL, bf16 wire)" % syncs) if args.merge == "hot" else
+                       "start-vertex shards, merge=%s" % args.merge), **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
                  "row_sharing": model.update_mode_name,
                  "pairs_per_step_global": pairs_all / K, "seconds_per_step": t_sgns / K},
