@@ -115,3 +115,21 @@ def test_bench_two_ranks_strong_scaling_reports_merge_timers(tmp_path):
     assert j["walk"]["steps_per_step_global"] == 100000 * 2 * 79        # the SAME job as N=1, split over the ranks
     assert j["merge_seconds"] > 0 and j["merges_per_step"] >= 1
     assert j["overlap_fraction"] is None or 0.0 <= j["overlap_fraction"] <= 1.0
+
+
+def test_bench_two_ranks_tiered_sum_merges(tmp_path):
+    """bench.py --gpus 2 --merge tsum over gloo on the one GPU: the tiered pure-sum merges through the real
+    communicator path (asynchronous all-reduces of row-list wire buffers, host-staged here)."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = 29050 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2",
+           "--rounds", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--backend", "gloo", "--merge", "tsum"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and "merge=tsum" in j["config"]["sharding"]
+    assert j["sgns"]["pairs_per_step_global"] > 1.5e8          # every pair of the 200 000 walks was trained once
