@@ -242,7 +242,7 @@ int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, i
                    float min_alpha, int64_t sentences_base, int64_t sentences_step,
                    int64_t sentences_total, int64_t alpha_batch, uint64_t seed, uint64_t walk_id_base,
                    unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
-                   void* stream);
+                   int32_t walk_splits, void* stream);
 
 /* ---- replica merges of the multi-GPU trainer (no counterpart in the reference, whose gensim
  * threads share one table: src/main.py:87 `workers=`) ------------------------------------------------------

@@ -54,7 +54,20 @@ struct SgnsArgs {
     uint64_t seed, walk_id_base;
     unsigned long long* pair_count;
     int32_t lpad;
+    int32_t splits;   // wavefronts per walk (>= 1): split s trains the centres [s*n/S, (s+1)*n/S) of the sentence
 };
+
+// x -> x advanced by k steps of the sentence's 48-bit LCG (composition of the affine map by squaring)
+__device__ __forceinline__ uint64_t lcg_skip(uint64_t x, uint64_t k) {
+    uint64_t cur_m = kLcgA, cur_c = kLcgC, acc_m = 1, acc_c = 0;
+    while (k) {
+        if (k & 1) { acc_m = (acc_m * cur_m) & kLcgMask; acc_c = (acc_c * cur_m + cur_c) & kLcgMask; }
+        cur_c = ((cur_m + 1) * cur_c) & kLcgMask;
+        cur_m = (cur_m * cur_m) & kLcgMask;
+        k >>= 1;
+    }
+    return (acc_m * x + acc_c) & kLcgMask;
+}
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
@@ -235,7 +248,15 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
     const int my_k = bitrev3(lane & 7);  // which of the 8 reduced values this lane ends up holding
     unsigned long long pairs_done = 0;
 
-    for (int64_t wi = (int64_t)blockIdx.x * 4 + wv; wi < a.n_walks; wi += n_waves) {
+    // Work items are (walk, split): with splits == 1 one wavefront owns a walk (gensim's worker owns a sentence); with
+    // S > 1 the centres of a sentence are dealt to S wavefronts — the same pairs, the same draws (the sentence's LCG is
+    // advanced to each split's first centre in closed form), only the order inside the sentence becomes a race like the
+    // one between sentences.  That is what lets a launch of a few hundred walks fill the chip (tiered merges).
+    const int S = a.splits;
+    const int64_t n_items = a.n_walks * S;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < n_items; item += n_waves) {
+        const int64_t wi = S == 1 ? item : item / S;
+        const int sp = S == 1 ? 0 : (int)(item - wi * S);
         const int len = a.lens ? a.lens[wi] : a.walk_stride;
         const uint64_t wid = a.walk_id_base + (uint64_t)wi;
         // ---- effective sentence: drop padding and sub-sampled words, keep order
@@ -263,8 +284,28 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
         alpha = fmaxf(alpha, a.min_alpha);
 
         uint64_t lcg = mix64(a.seed ^ mix64(wid + 0x632BE59BD9B4E019ULL)) & kLcgMask;
+        int i_begin = 0, i_end = n_eff;
+        if (S > 1) {
+            i_begin = (int)((int64_t)sp * n_eff / S);
+            i_end = (int)((int64_t)(sp + 1) * n_eff / S);
+            // draws of the centres before i_begin: `negative` per (centre, context) pair
+            int pairs_before = 0;
+            for (int base = 0; base < i_begin; base += 64) {
+                const int i = base + lane;
+                int np = 0;
+                if (i < i_begin) {
+                    const int rb = (int)(hash32(a.seed, wid, (uint32_t)i, 0xB17) % (uint32_t)a.window);
+                    const int lo = max(0, i - a.window + rb), hi = min(n_eff, i + a.window + 1 - rb);
+                    np = hi - lo > 1 ? hi - lo - 1 : 0;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o, 64);
+                pairs_before += np;
+            }
+            lcg = lcg_skip(lcg, (uint64_t)pairs_before * (uint64_t)a.negative);
+        }
 
-        for (int i = 0; i < n_eff; ++i) {
+        for (int i = i_begin; i < i_end; ++i) {
             const int32_t ci = __builtin_amdgcn_readfirstlane(sent[i]);
             const int rb = (int)(hash32(a.seed, wid, (uint32_t)i, 0xB17) % (uint32_t)a.window);
             const int lo = max(0, i - a.window + rb), hi = min(n_eff, i + a.window + 1 - rb);
@@ -593,7 +634,9 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
                               float min_alpha, int64_t sentences_base, int64_t sentences_step,
                               int64_t sentences_total, int64_t alpha_batch,
                               uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
-                              int32_t update_mode, int32_t max_blocks, void* stream) {
+                              int32_t update_mode, int32_t max_blocks, int32_t walk_splits, void* stream) {
+    if (walk_splits < 1 || walk_splits > walk_stride)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_splits %d outside [1, %d]", (int)walk_splits, (int)walk_stride);
     if (n_walks < 0 || walk_stride < 1 || n_words < 1 || dim < 1 || window < 1 || negative < 0 || negative > 64)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad size (walks %lld x %d, words %lld, dim %d, window %d, negative %d)",
                          (long long)n_walks, (int)walk_stride, (long long)n_words, (int)dim, (int)window, (int)negative);
@@ -609,6 +652,7 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     if (update_mode < kPlain || update_mode > kAtomic)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: update_mode %d", (int)update_mode);
     if (share && negative > 7) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: shared negatives need negative <= 7");
+    if (share && walk_splits != 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: shared negatives need walk_splits == 1");
     if (sentences_total < 1 || alpha_batch < 1 || sentences_step < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad schedule");
     hipStream_t st = (hipStream_t)stream;
     fill_exp_table();
@@ -626,9 +670,10 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     a.alpha_batch = alpha_batch;
     a.seed = seed; a.walk_id_base = walk_id_base; a.pair_count = pair_count;
     a.lpad = (walk_stride + 63) & ~63;
+    a.splits = walk_splits;
     const size_t shmem = (size_t)4 * a.lpad * sizeof(int32_t);
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
-    int64_t blocks = (n_walks + 3) / 4;
+    int64_t blocks = (n_walks * walk_splits + 3) / 4;
     // default grid: 256 CUs x 12 workgroups of 4 waves — every wave slot of the chip at this kernel's 36-40
     // VGPRs (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096 8.0e8, 6144 8.3e8) — but never more
     // than one wave per two vocabulary rows — beyond that the racing waves read each other's rows so stale that

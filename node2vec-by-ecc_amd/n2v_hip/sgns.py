@@ -133,13 +133,16 @@ class SgnsModel:
                                                   _lib.ptr(self.lut), self._stream()))
 
     def train_pass(self, walks, lens, sentences_base, sentences_total, walk_id_base, sentences_step=1,
-                   max_blocks=0):
-        """One kernel launch over `walks` (device int32 [n, L]); asynchronous."""
+                   max_blocks=0, splits=1):
+        """One kernel launch over `walks` (device int32 [n, L]); asynchronous.  splits: wavefronts per walk ("auto":
+        as many as it takes to put ~8 192 wavefronts on the chip, for the short launches of the tiered merges)."""
         assert walks.dtype == torch.int32 and walks.is_contiguous() and walks.device == self.device
         n, L = int(walks.shape[0]), int(walks.shape[1])
         if n == 0:
             return
         alpha_batch = max(1, MAX_WORDS_IN_BATCH // L)
+        if splits == "auto":
+            splits = max(1, min(L, -(-8192 // n)))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.n2v_sgns_train(
                 _lib.ptr(walks), _lib.ptr(lens), n, L, _lib.ptr(self.syn0), _lib.ptr(self.syn1neg), self.n_words,
@@ -147,7 +150,8 @@ class SgnsModel:
                 _lib.ptr(self.cum_table), _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha,
                 int(sentences_base), int(sentences_step), int(sentences_total), alpha_batch,
                 self.seed & (2**64 - 1),
-                int(walk_id_base), _lib.ptr(self.pair_count), self.update_mode, int(max_blocks), self._stream()))
+                int(walk_id_base), _lib.ptr(self.pair_count), self.update_mode, int(max_blocks), int(splits),
+                self._stream()))
 
     def pairs_trained(self):
         return int(self.pair_count.item())
@@ -649,7 +653,7 @@ def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, 
             if e > b:
                 model.train_pass(walks[b:e], None if lens is None else lens[b:e],
                                  sentences_base=ep * n_walks_global + b * world, sentences_step=world,
-                                 sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b)
+                                 sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b, splits="auto")
             level = plan.level_due(c)
             if level is not None:
                 merger.merge(level)
@@ -682,7 +686,7 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
                 # all replicas advance together: `b` local sentences = b * world global ones
                 model.train_pass(walks[b:e], None if lens is None else lens[b:e],
                                  sentences_base=ep * n_walks_global + b * world, sentences_step=world,
-                                 sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b)
+                                 sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b, splits="auto")
             merger.end_interval(last=(ep + 1 == epochs and i + 1 == len(chunks)))
     return merger
 
@@ -742,7 +746,8 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
                     b, e = subs[r][c]
                     if e > b:
                         m.train_pass(w[b:e], None if l is None else l[b:e], sentences_base=ep * n_walks_global + b * G,
-                                     sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b)
+                                     sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b,
+                                     splits="auto")
                 level = plan.level_due(c)
                 if level is None:
                     continue
@@ -765,7 +770,8 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
                 b, e = plans[r][c]
                 if e > b:
                     m.train_pass(w[b:e], None if l is None else l[b:e], sentences_base=ep * n_walks_global + b * G,
-                                 sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b)
+                                 sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b,
+                                     splits="auto")
             for mg in mergers:
                 mg.snapshot()
             if mergers[0].hot_wire is not None:

@@ -137,6 +137,29 @@ def test_pair_count_matches_window_rule(torch_cuda):
     assert 800 < per < 870, per  # 836 expected for L=80, window=10
 
 
+def test_walk_splits_train_the_same_pairs_and_stay_in_the_band(torch_cuda):
+    """walk_splits > 1 deals the centres of a sentence to several wavefronts (the short launches of the tiered merges
+    then fill the chip): exactly the same number of pairs, the same untouched rows, and — since only the ORDER inside a
+    sentence turns into a race — a link-prediction AUC inside the band of the sequential comparator."""
+    torch = torch_cuda
+    from n2v_hip import linkpred, sgns
+    g, corpus, counts, te_d, neg_d, rounds, auc_cpu = _band_case("uniform")
+    ref = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1)
+    ref.build_vocab(counts=counts)
+    ref.train_pass(corpus.walks, corpus.lens, sentences_base=0, sentences_total=corpus.walks.shape[0], walk_id_base=0)
+    for S in (2, 8, 80):
+        m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1)
+        m.build_vocab(counts=counts)
+        m.train_pass(corpus.walks, corpus.lens, sentences_base=0, sentences_total=corpus.walks.shape[0], walk_id_base=0,
+                     splits=S)
+        assert m.pairs_trained() == ref.pairs_trained(), S
+        auc = linkpred.get_roc_score(m.vectors(), te_d, neg_d)[0]
+        print("walk_splits %d: AUC %.5f vs sequential CPU %.5f (%+.5f)" % (S, auc, auc_cpu, auc - auc_cpu))
+        assert abs(auc - auc_cpu) <= AUC_BAND, (S, auc, auc_cpu)
+    with pytest.raises(Exception):
+        ref.train_pass(corpus.walks, corpus.lens, sentences_base=0, sentences_total=1, walk_id_base=0, splits=81)
+
+
 def test_untouched_rows_stay_put(torch_cuda):
     torch = torch_cuda
     from n2v_hip import sgns
