@@ -17,7 +17,7 @@ corpus = g.simulate_walks(2, 80)
 m = sgns.SgnsModel(cg.n_nodes, dim=128, window=10, negative=5, seed=1, update_mode="agent")
 m.build_vocab(corpus.walks)
 W = corpus.walks.shape[0]
-for size in (83, 334, 1335, 2298, 5342, 21368, 200000):
+for size, splits in [(sz, sp) for sz in (83, 334, 1335, 2298, 5342, 21368, 200000) for sp in (1, "auto")]:
     n_launch = max(4, min(200, 400000 // size))
     m.pair_count.zero_()
     torch.cuda.synchronize()
@@ -25,8 +25,10 @@ for size in (83, 334, 1335, 2298, 5342, 21368, 200000):
     a.record()
     for i in range(n_launch):
         lo = (i * size) % (W - size)
-        m.train_pass(corpus.walks[lo:lo + size], corpus.lens[lo:lo + size], sentences_base=lo, sentences_total=W, walk_id_base=lo)
+        m.train_pass(corpus.walks[lo:lo + size], corpus.lens[lo:lo + size], sentences_base=lo, sentences_total=W, walk_id_base=lo,
+                     splits=splits)
     b.record()
     torch.cuda.synchronize()
     dt = a.elapsed_time(b) / 1e3
-    print("launch of %6d walks: %.3e pairs/s (%d launches, %.1f us per launch)" % (size, m.pairs_trained() / dt, n_launch, dt / n_launch * 1e6), flush=True)
+    print("launch of %6d walks, walk_splits %-4s: %.3e pairs/s (%d launches, %.1f us per launch)" % (
+        size, splits, m.pairs_trained() / dt, n_launch, dt / n_launch * 1e6), flush=True)
