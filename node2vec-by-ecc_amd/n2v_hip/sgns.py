@@ -569,19 +569,21 @@ class TieredSumMerger:
         self.base = [t.clone() for t in self.t]
         stride = int(self.t[0].shape[1])
         self.ones = [torch.ones(int(t.shape[0]), dtype=torch.float32, device=dev) for t in self.t]
-        self.wire = [torch.zeros((int(t.shape[0]), stride), dtype=wire, device=dev) for t in self.t]
+        # ONE wire buffer for all tables (their due rows back to back): one collective per merge
+        self.wire = torch.zeros((sum(int(t.shape[0]) for t in self.t), stride), dtype=wire, device=dev)
         self.n_merges = [0] * plan.n_tiers
 
     def pack(self, level):
-        """-> the wire views holding this rank's changes of the rows of tiers >= level (one per table, may be empty)."""
-        views = []
+        """-> (wire slice holding this rank's changes of the rows of tiers >= level of every table, per-table views)."""
+        views, o = [], 0
         for i, t in enumerate(self.t):
             rows = self.plan.rows_ge[i][level]
-            v = self.wire[i][: int(rows.numel())]
+            v = self.wire[o:o + int(rows.numel())]
             if rows.numel():
                 self.ops.pack_rows(t, self.base[i], rows, v)
             views.append(v)
-        return views
+            o += int(rows.numel())
+        return self.wire[:o], views
 
     def apply(self, level, views):
         for i, t in enumerate(self.t):
@@ -591,11 +593,11 @@ class TieredSumMerger:
         self.n_merges[level] += 1
 
     def merge(self, level):
-        views = self.pack(level)
-        handles = [self.comm.all_reduce_async(v) if v.numel() else None for v in views]
-        for h in handles:
-            if h is not None:
-                h.wait()
+        flat, views = self.pack(level)
+        if flat.numel():
+            handle = self.comm.all_reduce_async(flat)
+            if handle is not None:
+                handle.wait()
         self.apply(level, views)
 
 
@@ -751,11 +753,10 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
                 level = plan.level_due(c)
                 if level is None:
                     continue
-                views = [mg.pack(level) for mg in mergers]
-                for i in range(2):
-                    if views[0][i].numel():
-                        _SimGroup.reduce([v[i] for v in views])
-                for mg, v in zip(mergers, views):
+                packed = [mg.pack(level) for mg in mergers]
+                if packed[0][0].numel():
+                    _SimGroup.reduce([flat for flat, _ in packed])
+                for mg, (_, v) in zip(mergers, packed):
                     mg.apply(level, v)
         return n_chunks
     n_chunks, plan = _merge_setup(models[0], L, n_walks_global, G, syncs_per_epoch, merge, cold_delay)

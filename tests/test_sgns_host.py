@@ -196,9 +196,9 @@ def test_tiered_sum_merger_applies_every_change_once():
                 tabs[r] += incr[c, r]
             level = plan.level_due(c)
             assert level is not None
-            views = [mg.pack(level) for mg in mergers]
-            sgns._SimGroup.reduce([v[0] for v in views])
-            for mg, v in zip(mergers, views):
+            packed = [mg.pack(level) for mg in mergers]
+            sgns._SimGroup.reduce([flat for flat, _ in packed])
+            for mg, (_, v) in zip(mergers, packed):
                 mg.apply(level, v)
             hot = plan.rows_ge[0][level]
             for t in tabs[1:]:
