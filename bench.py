@@ -238,9 +238,10 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = BASELINE config C4 (the SAME rounds x N_nodes walks, start positions split "
                          "over the ranks, src/main_link.py:261-264); weak = every rank walks rounds x N_nodes")
-    ap.add_argument("--merge", default="hot", choices=["hot", "tsum", "delta", "avg"],
-                    help="N > 1: replica merges — 'hot' (per-row weights, few merges: the throughput default) or 'tsum' (pure "
-                         "sums at per-row cadences: meets the AUC band at every size in simulation, short launches)")
+    ap.add_argument("--merge", default="tsum", choices=["tsum", "hot", "delta", "avg"],
+                    help="N > 1: replica merges — 'tsum' (default: pure sums at per-row cadences, inside the AUC band at every "
+                         "size measured; many short launches) or 'hot' (per-row weights, 117 merges per pass at 8 GPUs: "
+                         "several times faster, inside the band on small graphs only)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for the cold rows' all-reduce at once instead of under the next interval (A/B)")
     ap.add_argument("--update-mode", default="auto", choices=["auto", "atomic", "agent", "plain"],
@@ -313,7 +314,7 @@ def main():
         mg = sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
                         syncs_per_epoch=syncs if args.merge != "tsum" else "auto", merge=args.merge,
                         overlap=not args.no_overlap)
-        if timed and isinstance(mg, sgns.ReplicaMerger):
+        if timed and mg is not None:
             if mergers:
                 mergers[-1].release()       # keep the timers, not 2.5 GB of snapshots per timed step
             mergers.append(mg)
@@ -352,13 +353,12 @@ def main():
         sec = mg.seconds()
         merge_secs["merge"] += sec["merge"]
         merge_secs["wait"] += sec["wait"]
-        merge_secs["n"] += mg.n_merges
+        merge_secs["n"] += mg.n_merges if isinstance(mg.n_merges, int) else sum(mg.n_merges)   # tsum: all tiers' merges
     comm_probe = None
     if world > 1 and mergers:
         # what one merge's all-reduce costs when nothing runs beside it (for overlap_fraction): the wire buffer that
         # carries the bulk of the rows — the synchronous tier's unless most rows are in the delayed tier
-        mg0 = mergers[-1]
-        buf = mg0.hot_wire if (mg0.hot_wire is not None and (not mg0.has_cold or sum(mg0.plan.n_hot) >= sum(mg0.plan.n_cold))) else mg0.cold_wire[0]
+        buf = mergers[-1].probe_buffer()
         comm.all_reduce_sum(buf)
         torch.cuda.synchronize()
         c0, c1 = ev(), ev()
@@ -447,6 +447,9 @@ def main():
                    "sharding": "single GPU" if world == 1 else (
                        ("start-vertex shards, %d 'hot'-weighted synchronous merges per SGNS pass, pipelined over row "
                         "ranges (RCCL, bf16 wire)" % syncs) if args.merge == "hot" else
+                       "start-vertex shards, merge=tsum: pure-sum merges at per-row cadences (%d tiers x%d, base "
+                       "staleness budget %d), one RCCL all-reduce (bf16 wire) per merge" % (
+                           sgns.TSUM_TIERS, sgns.TSUM_RATIO, sgns.TSUM_STALENESS_BUDGET) if args.merge == "tsum" else
                        "start-vertex shards, merge=%s" % args.merge), **info},
         "sgns": {"metric": "SGNS pair-updates/s", "value": pair_rate, "unit": "pair-updates/s",
                  "row_sharing": model.update_mode_name,
@@ -463,8 +466,9 @@ def main():
         "merge_wait_seconds": merge_secs["wait"] / K if world > 1 else None,
         "merges_per_step": merge_secs["n"] / K if world > 1 else None,
         "allreduce_seconds_standalone": comm_probe,
-        "overlap_fraction": (max(0.0, 1.0 - merge_secs["wait"] / max(comm_probe * merge_secs["n"], 1e-12))
-                             if comm_probe else None),
+        # tsum merges are synchronous (pack -> all-reduce -> apply between two training launches): nothing is hidden
+        "overlap_fraction": (None if not comm_probe else 0.0 if args.merge == "tsum" else
+                             max(0.0, 1.0 - merge_secs["wait"] / max(comm_probe * merge_secs["n"], 1e-12))),
         # dominant kernel by time: sgns_kernel
         "roofline": {"kernel": "sgns_kernel", "bound": "hbm", "achieved": sgns_bytes_launch / sgns_launch_s / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -92,7 +92,7 @@ def learn_embeddings(walks, **overrides):
         ctx.comm.all_reduce_sum(tot)
         b, _ = _sgns.shard_bounds(overrides["n_starts"], ctx.world, ctx.rank)
         _dist.train_sharded(model, corpus.walks, corpus.lens, ctx, n_walks_global=int(tot.item()),
-                            shard_offset=b * overrides["num_walks"], epochs=epochs, merge=overrides.get("merge", "hot"))
+                            shard_offset=b * overrides["num_walks"], epochs=epochs, merge=overrides.get("merge", "tsum"))
     wv = _sgns.KeyedVectors(corpus.labels, model.counts, model.vectors().cpu().numpy())
     return _sgns.Word2VecResult(wv, model, model.pairs_trained())
 

@@ -122,7 +122,7 @@ def global_counts(walks, n_words, ctx):
 
 
 def train_sharded(model, walks, lens, ctx, n_walks_global, shard_offset, epochs=1, syncs_per_epoch="auto",
-                  merge="hot", overlap=True, cold_delay=False):
+                  merge="tsum", overlap=True, cold_delay=False):
     """sgns.train with this rank's communicator; afterwards every rank holds the merged tables.  Returns the
     ReplicaMerger (its timers: bench.py's merge_seconds / overlap_fraction)."""
     assert model.device == ctx.device, "replica on %s but this rank owns %s" % (model.device, ctx.device)

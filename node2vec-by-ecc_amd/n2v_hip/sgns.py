@@ -425,6 +425,12 @@ class ReplicaMerger:
         """Drop the buffers (the timers stay readable)."""
         self.xs = self.base = self.hot_wire = self.hot_views = self.cold_wire = self.cold_views = None
 
+    def probe_buffer(self):
+        """The wire buffer that carries the bulk of the rows (bench.py times one stand-alone all-reduce of it)."""
+        if self.hot_wire is not None and (not self.has_cold or sum(self.plan.n_hot) >= sum(self.plan.n_cold)):
+            return self.hot_wire
+        return self.cold_wire[0]
+
     def _wait_pending(self):
         if self.pending is None:
             return None
@@ -572,6 +578,31 @@ class TieredSumMerger:
         # ONE wire buffer for all tables (their due rows back to back): one collective per merge
         self.wire = torch.zeros((sum(int(t.shape[0]) for t in self.t), stride), dtype=wire, device=dev)
         self.n_merges = [0] * plan.n_tiers
+        self._ev = []
+        self._timed = dev.type == "cuda"
+
+    def _mark(self):
+        if not self._timed:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def seconds(self):
+        """{'merge': compute-stream seconds inside the merges, 'wait': of which waiting for the all-reduce}."""
+        if self._timed:
+            torch.cuda.synchronize(self.t[0].device)
+        out = {"merge": 0.0, "wait": 0.0}
+        for kind, a, b in self._ev:
+            out[kind] += a.elapsed_time(b) / 1e3
+        out["merge"] += out["wait"]
+        return out
+
+    def release(self):
+        self.base = self.wire = self.ones = None
+
+    def probe_buffer(self):
+        return self.wire
 
     def pack(self, level):
         """-> (wire slice holding this rank's changes of the rows of tiers >= level of every table, per-table views)."""
@@ -593,12 +624,17 @@ class TieredSumMerger:
         self.n_merges[level] += 1
 
     def merge(self, level):
+        t0 = self._mark()
         flat, views = self.pack(level)
+        t1 = self._mark()
         if flat.numel():
             handle = self.comm.all_reduce_async(flat)
             if handle is not None:
                 handle.wait()
+        t2 = self._mark()
         self.apply(level, views)
+        if self._timed:
+            self._ev += [("merge", t0, t1), ("wait", t1, t2), ("merge", t2, self._mark())]
 
 
 def auto_syncs(tokens_global, n_words, world):
@@ -663,10 +699,12 @@ def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, 
 
 
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
-          merge="hot", overlap=True, cold_delay=False, ops=None):
-    """Train `epochs` passes over this rank's walks.  With a communicator the replicas are merged
-    `syncs_per_epoch` times per pass ("auto": auto_syncs) by a ReplicaMerger — or, merge="tsum", by pure sums at
-    per-row cadences (TieredSumMerger); returns the merger (None on one GPU) so that the caller can read its timers."""
+          merge="tsum", overlap=True, cold_delay=False, ops=None):
+    """Train `epochs` passes over this rank's walks.  With a communicator the replicas are merged: merge="tsum"
+    (default) by pure sums at per-row cadences (TieredSumMerger) — the scheme that stays inside the AUC band at
+    every graph size measured —, merge="hot" by per-row-weighted sums at `syncs_per_epoch` merges per pass
+    (ReplicaMerger; several times faster at 8 GPUs, inside the band on the small probe graphs, 0.003-0.006 off at
+    131k nodes).  Returns the merger (None on one GPU) so that the caller can read its timers."""
     n_local = int(walks.shape[0])
     if n_walks_global is None:
         n_walks_global = n_local
@@ -727,7 +765,7 @@ class _SimGroup:
             t.copy_(acc)
 
 
-def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="hot", epochs=1,
+def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="tsum", epochs=1,
                              cold_delay=False, wire_dtype=torch.bfloat16):
     """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens, shard_offset)` what
     rank r would hold.  Runs the schedule of `train` with one ReplicaMerger per replica — the same kernels, the

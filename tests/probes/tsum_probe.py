@@ -25,7 +25,7 @@ neg_d = np.stack([g.dense_of(neg[:, 0]), g.dense_of(neg[:, 1])], 1)
 n = g.n_nodes
 counts = torch.bincount(corpus.walks.reshape(-1).long(), minlength=n)
 for G in [int(x) for x in os.environ.get("GS", "8").split(",")]:
-    for wire in (torch.float32, torch.bfloat16):
+    for wire in (torch.bfloat16,):
         for theta in [float(x) for x in os.environ.get("THETAS", "500,125").split(",")]:
             for budget in [float(x) for x in os.environ.get("BUDGETS", "24").split(",")]:
                 sgns.TSUM_THETA, sgns.TSUM_STALENESS_BUDGET = theta, budget
@@ -40,11 +40,11 @@ for G in [int(x) for x in os.environ.get("GS", "8").split(",")]:
                 t = time.time()
                 # SumTierPlan reads the module constants at call time through its defaults -> pass explicitly
                 orig = sgns.SumTierPlan.__init__.__defaults__
-                sgns.SumTierPlan.__init__.__defaults__ = (theta,) + orig[1:]
+                sgns.SumTierPlan.__init__.__defaults__ = (theta, int(os.environ.get("TIERS", orig[1]))) + orig[2:]
                 ns = sgns.train_simulated_replicas(models, shards, n_walks_global=corpus.walks.shape[0], merge="tsum",
                                                    wire_dtype=wire)
                 sgns.SumTierPlan.__init__.__defaults__ = orig
                 torch.cuda.synchronize()
                 auc = linkpred.get_roc_score(models[0].vectors(), te_d, neg_d)[0]
-                print("[%s] G=%d wire=%s theta=%g budget=%g base syncs=%d: AUC %.5f (%+.5f) %.0fs" % (
-                    kind, G, str(wire).split(".")[-1], theta, budget, ns, auc, auc - seq, time.time() - t), flush=True)
+                print("[%s] G=%d tiers=%s theta=%g budget=%g base syncs=%d: AUC %.5f (%+.5f) %.0fs" % (
+                    kind, G, os.environ.get("TIERS", "4"), theta, budget, ns, auc, auc - seq, time.time() - t), flush=True)

@@ -105,7 +105,7 @@ def test_bench_two_ranks_strong_scaling_reports_merge_timers(tmp_path):
     port = 29100 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2",
-           "--rounds", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo"]
+           "--rounds", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo", "--merge", "hot"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -131,5 +131,5 @@ def test_bench_two_ranks_tiered_sum_merges(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert j["n_gpus"] == 2 and "merge=tsum" in j["config"]["sharding"]
+    assert j["n_gpus"] == 2 and "merge=tsum" in j["config"]["sharding"] and j["merge_seconds"] > 0
     assert j["sgns"]["pairs_per_step_global"] > 1.5e8          # every pair of the 200 000 walks was trained once

@@ -306,8 +306,8 @@ _EDGE = pytest.mark.xfail(strict=False, reason="four replicas on the uniform gra
 @pytest.mark.parametrize("kind,G", [("uniform", 1), ("uniform", 2), pytest.param("uniform", 4, marks=_EDGE), ("uniform", 8),
                                     ("hub", 1), ("hub", 2), ("hub", 4), ("hub", 8)])
 def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, kind, G):
-    """The multi-GPU scheme (start-vertex shards, one replica per rank, 'hot'-weighted merges at the auto_syncs
-    cadence, synchronous merges, bf16 wire) scored on ONE GPU by training G
+    """merge="hot", the faster optional multi-GPU scheme (start-vertex shards, one replica per rank, 'hot'-weighted
+    merges at the auto_syncs cadence, synchronous merges, bf16 wire) scored on ONE GPU by training G
     replicas interval by interval with the same ReplicaMerger, kernels and schedule as n2v_hip.sgns.train: AUC
     within +-0.002 of the sequential CPU comparator on a uniform and on a hub-heavy graph (C4 is power-law)."""
     torch = torch_cuda
@@ -326,7 +326,7 @@ def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, kind, G):
         sgns.train(models[0], corpus.walks, corpus.lens, epochs=1)
         n_syncs = 0
     else:
-        n_syncs = sgns.train_simulated_replicas(models, shards, n_walks_global=corpus.walks.shape[0])
+        n_syncs = sgns.train_simulated_replicas(models, shards, n_walks_global=corpus.walks.shape[0], merge="hot")
     torch.cuda.synchronize()
     for m in models[1:]:
         assert torch.equal(m.syn0, models[0].syn0) and torch.equal(m.syn1neg, models[0].syn1neg)
@@ -337,7 +337,7 @@ def test_multi_gpu_scheme_auc_within_band_simulated(torch_cuda, kind, G):
 
 @pytest.mark.parametrize("kind,G", [("uniform", 2), ("uniform", 8), ("hub", 4)])
 def test_tiered_sum_merges_auc_within_band_simulated(torch_cuda, kind, G):
-    """merge="tsum" — pure sums at per-row cadences (every row 234 times per pass at 8 replicas, hub rows 4 / 16 / 64
+    """merge="tsum", the default — pure sums at per-row cadences (every row 234 times per pass at 8 replicas, hub rows 4 / 16 / 64
     times as often), no damping, no fitted weights: inside the band on both graphs.  The hub graph at 8 replicas
     (-0.0001, three minutes of Python-driven launches) is in profiles/r02/logs/pytest_sgns_band.log and
     tests/probes/tsum_probe.py; on a 131 072-node hub graph the scheme is at -0.0002 where the damped default is at
