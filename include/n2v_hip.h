@@ -272,6 +272,20 @@ int n2v_merge_flush(float* x, float* xs, float* base, int64_t n_rows, int32_t st
  * are due); after the all-reduce n2v_merge_hot_apply (w == 1, xs == x) folds the sum into base and resets x.       */
 int n2v_merge_pack_rows(const float* x, const float* base, int32_t stride, const int64_t* rows, int64_t n_list,
                         void* wire, int32_t wire_bf16, void* stream);
+/* The same two steps for ALL tables of a merge in one launch each (the hub tiers are merged thousands of times per pass
+ * and hold few rows: the launches are what they cost).  tabs[t]: table and base fp32[*][stride], the row list (NULL:
+ * every row 0 .. n_rows-1 in order) and its length; the wire buffer holds the lists back to back, [sum n_rows][stride].
+ * n2v_tsum_pack: wire[j] = table[row] - base[row];  n2v_tsum_apply: base[row] += wire[j], table[row] = base[row].   */
+#define N2V_TSUM_MAX_TABLES 4
+typedef struct {
+    float* table;
+    float* base;
+    const int64_t* rows;
+    int64_t n_rows;
+} n2v_tsum_table;
+int n2v_tsum_pack(const n2v_tsum_table* tabs, int32_t n_tabs, int32_t stride, void* wire, int32_t wire_bf16, void* stream);
+int n2v_tsum_apply(const n2v_tsum_table* tabs, int32_t n_tabs, int32_t stride, const void* wire, int32_t wire_bf16,
+                   void* stream);
 
 #ifdef __cplusplus
 }

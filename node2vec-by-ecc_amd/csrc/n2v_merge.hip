@@ -100,6 +100,78 @@ merge_pack_rows_kernel(const float* __restrict__ x, const float* __restrict__ ba
     for (int c = lane; c < stride; c += 64) wire_store<BF16>(wire, j * stride + c, x[o + c] - base[o + c]);
 }
 
+// Tiered sums, all tables of a merge in ONE launch (the hub tiers are merged ~15 000 times per pass at 8 GPUs and hold
+// a few thousand rows: launch count, not bytes, is what they cost).  Wire row j of the launch belongs to table t
+// (first[t] <= j < first[t+1]), list position j - first[t]; rows == NULL: the list is every row in order.
+struct TsumTabs {
+    float* x[N2V_TSUM_MAX_TABLES];
+    float* base[N2V_TSUM_MAX_TABLES];
+    const int64_t* rows[N2V_TSUM_MAX_TABLES];
+    int64_t first[N2V_TSUM_MAX_TABLES + 1];
+    int n_tabs;
+    int stride;
+};
+
+template <bool BF16, bool APPLY>
+__global__ void __launch_bounds__(256) tsum_kernel(TsumTabs a, void* __restrict__ wire) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (j >= a.first[a.n_tabs]) return;
+    // constant indices only: a run-time index into the argument struct would send it through scratch memory
+    float* __restrict__ x = a.x[0];
+    float* __restrict__ base = a.base[0];
+    const int64_t* __restrict__ rows = a.rows[0];
+    int64_t first = 0;
+#pragma unroll
+    for (int t = 1; t < N2V_TSUM_MAX_TABLES; ++t)
+        if (t < a.n_tabs && j >= a.first[t]) { x = a.x[t]; base = a.base[t]; rows = a.rows[t]; first = a.first[t]; }
+    const int64_t k = j - first;
+    const int64_t o = (rows ? rows[k] : k) * a.stride;
+    for (int c = lane; c < a.stride; c += 64) {
+        if (APPLY) {
+            const float b = base[o + c] + wire_load<BF16>(wire, j * a.stride + c);
+            base[o + c] = b;
+            x[o + c] = b;
+        } else {
+            wire_store<BF16>(wire, j * a.stride + c, x[o + c] - base[o + c]);
+        }
+    }
+}
+
+int tsum_launch(const char* what, const n2v_tsum_table* tabs, int32_t n_tabs, int32_t stride, void* wire, int32_t wire_bf16,
+                bool apply, void* stream) {
+    if (n_tabs < 0 || n_tabs > N2V_TSUM_MAX_TABLES || stride < 1) return n2v::fail(N2V_ERR_INVALID, "%s: bad sizes", what);
+    if (n_tabs && !tabs) return n2v::fail(N2V_ERR_INVALID, "%s: null pointer", what);
+    TsumTabs a{};
+    a.n_tabs = n_tabs;
+    a.stride = stride;
+    int64_t total = 0;
+    for (int t = 0; t < n_tabs; ++t) {
+        if (tabs[t].n_rows < 0) return n2v::fail(N2V_ERR_INVALID, "%s: negative row count", what);
+        if (tabs[t].n_rows && (!tabs[t].table || !tabs[t].base)) return n2v::fail(N2V_ERR_INVALID, "%s: null table", what);
+        a.x[t] = tabs[t].table;
+        a.base[t] = tabs[t].base;
+        a.rows[t] = tabs[t].rows;
+        a.first[t] = total;
+        total += tabs[t].n_rows;
+    }
+    for (int t = n_tabs; t <= N2V_TSUM_MAX_TABLES; ++t) a.first[t] = total;
+    if (total == 0) return N2V_OK;
+    if (!wire) return n2v::fail(N2V_ERR_INVALID, "%s: null wire buffer", what);
+    const int64_t blocks = (total + 3) / 4;
+    if (blocks > 0x7fffffff) return n2v::fail(N2V_ERR_INVALID, "%s: too many rows", what);
+    const dim3 g((unsigned)blocks), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (apply) {
+        if (wire_bf16) hipLaunchKernelGGL((tsum_kernel<true, true>), g, b, 0, s, a, wire);
+        else hipLaunchKernelGGL((tsum_kernel<false, true>), g, b, 0, s, a, wire);
+    } else {
+        if (wire_bf16) hipLaunchKernelGGL((tsum_kernel<true, false>), g, b, 0, s, a, wire);
+        else hipLaunchKernelGGL((tsum_kernel<false, false>), g, b, 0, s, a, wire);
+    }
+    return n2v::check_launch(what);
+}
+
 int rows_grid(int64_t n, unsigned* blocks) {
     const int64_t b = (n + 3) / 4;
     if (b > 0x7fffffff) return -1;
@@ -167,4 +239,14 @@ extern "C" int n2v_merge_pack_rows(const float* x, const float* base, int32_t st
     else hipLaunchKernelGGL((merge_pack_rows_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, base, (int)stride,
                             rows, n_list, wire);
     return n2v::check_launch("n2v_merge_pack_rows");
+}
+
+extern "C" int n2v_tsum_pack(const n2v_tsum_table* tabs, int32_t n_tabs, int32_t stride, void* wire, int32_t wire_bf16,
+                             void* stream) {
+    return tsum_launch("n2v_tsum_pack", tabs, n_tabs, stride, wire, wire_bf16, false, stream);
+}
+
+extern "C" int n2v_tsum_apply(const n2v_tsum_table* tabs, int32_t n_tabs, int32_t stride, const void* wire,
+                              int32_t wire_bf16, void* stream) {
+    return tsum_launch("n2v_tsum_apply", tabs, n_tabs, stride, const_cast<void*>(wire), wire_bf16, true, stream);
 }

@@ -23,6 +23,7 @@
 // gensim's Hogwild worker threads race with each other.  The path is HBM/L2 gather-scatter
 // bound; there is no dense contraction worth an MFMA.
 #include <cmath>
+#include <mutex>
 
 #include "n2v_common.h"
 
@@ -603,6 +604,25 @@ void fill_exp_table() {
     host_exp_ready = true;
 }
 
+// The sigmoid table reaches each device's constant memory once per process (a blocking copy the first time a device
+// trains): re-uploading it with every launch cost a 4-KB copy kernel and ~20 us of host time per launch, which the
+// thousands of short launches of the tiered merges pay in full.
+std::mutex exp_upload_mutex;
+bool exp_uploaded[64] = {};
+
+int upload_exp_table() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) return n2v::fail(N2V_ERR_HIP, "n2v_sgns_train: hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(exp_upload_mutex);
+    if (exp_uploaded[dev]) return N2V_OK;
+    fill_exp_table();
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_exp_table), host_exp_table, sizeof(host_exp_table), 0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return n2v::fail(N2V_ERR_HIP, "n2v_sgns_train: exp table upload: %s", hipGetErrorString(e));
+    exp_uploaded[dev] = true;
+    return N2V_OK;
+}
+
 }  // namespace
 
 extern "C" int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bits, uint32_t* lut,
@@ -655,10 +675,7 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     if (share && walk_splits != 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: shared negatives need walk_splits == 1");
     if (sentences_total < 1 || alpha_batch < 1 || sentences_step < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad schedule");
     hipStream_t st = (hipStream_t)stream;
-    fill_exp_table();
-    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_exp_table), host_exp_table, sizeof(host_exp_table), 0,
-                                          hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return n2v::fail(N2V_ERR_HIP, "n2v_sgns_train: exp table upload: %s", hipGetErrorString(e));
+    if (int rc = upload_exp_table()) return rc;
 
     SgnsArgs a;
     a.walks = walks; a.lens = lens; a.n_walks = n_walks; a.walk_stride = walk_stride;

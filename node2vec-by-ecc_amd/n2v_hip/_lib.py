@@ -53,6 +53,8 @@ SIGNATURES = {
     "n2v_merge_hot_apply": (C.c_int, [_ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i64, _ptr, _i32, _ptr]),
     "n2v_merge_flush": (C.c_int, [_ptr, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _ptr, _i32, _ptr]),
     "n2v_merge_pack_rows": (C.c_int, [_ptr, _ptr, _i32, _ptr, _i64, _ptr, _i32, _ptr]),
+    "n2v_tsum_pack": (C.c_int, [_ptr, _i32, _i32, _ptr, _i32, _ptr]),
+    "n2v_tsum_apply": (C.c_int, [_ptr, _i32, _i32, _ptr, _i32, _ptr]),
     # include/n2v_bine.h
     "n2v_bine_spmv": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "n2v_bine_hits_normalise": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr]),

@@ -13,6 +13,8 @@ Multi-GPU: every rank trains a full replica on its shard of the
 all-reduced over RCCL at sync points inside the epoch and at its end; the learning-rate
 schedule is driven by the GLOBAL sentence count.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -140,18 +142,39 @@ class SgnsModel:
         n, L = int(walks.shape[0]), int(walks.shape[1])
         if n == 0:
             return
-        alpha_batch = max(1, MAX_WORDS_IN_BATCH // L)
+        with torch.cuda.device(self.device):
+            self._launch(_lib.ptr(walks), _lib.ptr(lens), n, L, sentences_base, sentences_step, sentences_total,
+                         walk_id_base, max_blocks, splits, self._stream())
+
+    def _launch(self, walks_ptr, lens_ptr, n, L, sentences_base, sentences_step, sentences_total, walk_id_base,
+                max_blocks, splits, stream):
         if splits == "auto":
             splits = max(1, min(L, -(-8192 // n)))
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.n2v_sgns_train(
-                _lib.ptr(walks), _lib.ptr(lens), n, L, _lib.ptr(self.syn0), _lib.ptr(self.syn1neg), self.n_words,
-                self.dim, self.stride, self.window, self.negative, _lib.ptr(self.sample_int),
-                _lib.ptr(self.cum_table), _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha,
-                int(sentences_base), int(sentences_step), int(sentences_total), alpha_batch,
-                self.seed & (2**64 - 1),
-                int(walk_id_base), _lib.ptr(self.pair_count), self.update_mode, int(max_blocks), int(splits),
-                self._stream()))
+        _lib.check(self.lib.n2v_sgns_train(
+            walks_ptr, lens_ptr, n, L, _lib.ptr(self.syn0), _lib.ptr(self.syn1neg), self.n_words,
+            self.dim, self.stride, self.window, self.negative, _lib.ptr(self.sample_int),
+            _lib.ptr(self.cum_table), _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha,
+            int(sentences_base), int(sentences_step), int(sentences_total), max(1, MAX_WORDS_IN_BATCH // L),
+            self.seed & (2**64 - 1),
+            int(walk_id_base), _lib.ptr(self.pair_count), self.update_mode, int(max_blocks), int(splits), stream))
+
+    def span_trainer(self, walks, lens, sentences_total, sentences_step, splits="auto"):
+        """-> launch(b, e, sentences_base, walk_id_base): train_pass over walks[b:e] without building tensor views —
+        for drivers that issue thousands of short launches per pass (the tiered merges).  The caller holds
+        torch.cuda.device(self.device) and keeps `walks` / `lens` alive."""
+        assert walks.dtype == torch.int32 and walks.is_contiguous() and walks.device == self.device
+        L = int(walks.shape[1])
+        wp = walks.data_ptr()
+        lp = None if lens is None else lens.data_ptr()
+        if lens is not None:
+            assert lens.dtype == torch.int32 and lens.is_contiguous()
+        dev = self.device
+
+        def launch(b, e, sentences_base, walk_id_base):
+            if e > b:
+                self._launch(wp + b * L * 4, None if lp is None else lp + b * 4, e - b, L, sentences_base, sentences_step,
+                             sentences_total, walk_id_base, 0, splits, _lib.stream_ptr(dev))
+        return launch
 
     def pairs_trained(self):
         return int(self.pair_count.item())
@@ -342,6 +365,28 @@ class HipMergeOps:
             _lib.check(self.lib.n2v_merge_pack_rows(
                 _lib.ptr(x), _lib.ptr(base), int(x.shape[1]), _lib.ptr(rows), int(rows.numel()), _lib.ptr(wire),
                 self._bf16(wire), _lib.stream_ptr(x.device)))
+
+    class _TsumTable(ctypes.Structure):       # n2v_tsum_table of include/n2v_hip.h
+        _fields_ = [("table", ctypes.c_void_p), ("base", ctypes.c_void_p), ("rows", ctypes.c_void_p),
+                    ("n_rows", ctypes.c_int64)]
+
+    def tsum_tables(self, tables, bases, row_lists):
+        """The n2v_tsum_table array of one merge level (row_lists[i] None: every row of table i).  The caller keeps
+        the tensors alive."""
+        arr = (self._TsumTable * len(tables))()
+        for i, (t, b, rows) in enumerate(zip(tables, bases, row_lists)):
+            self._check(t)
+            assert t.dtype == torch.float32 and t.is_contiguous() and b.is_contiguous() and b.shape == t.shape
+            arr[i].table, arr[i].base = t.data_ptr(), b.data_ptr()
+            arr[i].rows = None if rows is None else rows.data_ptr()
+            arr[i].n_rows = int(t.shape[0]) if rows is None else int(rows.numel())
+        return arr
+
+    def tsum_pack(self, arr, stride, wire, stream):
+        _lib.check(self.lib.n2v_tsum_pack(arr, len(arr), stride, wire.data_ptr(), self._bf16(wire), stream))
+
+    def tsum_apply(self, arr, stride, wire, stream):
+        _lib.check(self.lib.n2v_tsum_apply(arr, len(arr), stride, wire.data_ptr(), self._bf16(wire), stream))
 
     def flush(self, x, xs, base, w, hot_pos, sum_last):
         self._check(x)
@@ -542,16 +587,16 @@ class SumTierPlan:
     def __init__(self, counts, interval_tokens_global, world, window, negative, device, theta=TSUM_THETA,
                  n_tiers=TSUM_TIERS, ratio=TSUM_RATIO):
         self.n_tiers, self.ratio, self.world = int(n_tiers), int(ratio), world
-        self.sub = self.ratio ** (self.n_tiers - 1)          # sub-intervals per base interval
-        self.tier, self.rows_ge = [], []
+        self.tier = []
         for upd in expected_updates(counts, interval_tokens_global, window, negative, device):
             u = (world - 1) / world * upd
             t = torch.ceil(torch.log(u.clamp_min(1e-30) / theta) / np.log(self.ratio)).clamp(0, self.n_tiers - 1).long()
-            t = torch.where(u > theta, t.clamp_min(1), torch.zeros_like(t))
-            self.tier.append(t)
-            n = int(u.numel())
-            self.rows_ge.append([torch.arange(n, dtype=torch.int64, device=device)] +
-                                [torch.nonzero(t >= j).flatten().contiguous() for j in range(1, self.n_tiers)])
+            self.tier.append(torch.where(u > theta, t.clamp_min(1), torch.zeros_like(t)))
+        # tiers nobody is in are dropped (a graph without hubs: one tier, no sub-intervals, full-size launches)
+        self.n_tiers = 1 + max(int(t.max()) if t.numel() else 0 for t in self.tier)
+        self.sub = self.ratio ** (self.n_tiers - 1)          # sub-intervals per base interval
+        self.rows_ge = [[torch.arange(int(t.numel()), dtype=torch.int64, device=device)] +
+                        [torch.nonzero(t >= j).flatten().contiguous() for j in range(1, self.n_tiers)] for t in self.tier]
 
     def level_due(self, sub_index):
         """The coarsest tier level whose merge is due after sub-interval `sub_index` (0-based, global), or None:
@@ -580,6 +625,16 @@ class TieredSumMerger:
         self.n_merges = [0] * plan.n_tiers
         self._ev = []
         self._timed = dev.type == "cuda"
+        # all tables of a level in one launch per step (n2v_tsum_pack / n2v_tsum_apply), arguments prepared once:
+        # the hub tiers' merges are launch- and host-bound
+        self.fused = hasattr(self.ops, "tsum_pack") and dev.type == "cuda"
+        if self.fused:
+            self._stride = stride
+            self._args, self._flat = [], []
+            for level in range(plan.n_tiers):
+                lists = [None if level == 0 else plan.rows_ge[i][level] for i in range(len(self.t))]
+                self._args.append(self.ops.tsum_tables(self.t, self.base, lists))
+                self._flat.append(self.wire[:sum(int(plan.rows_ge[i][level].numel()) for i in range(len(self.t)))])
 
     def _mark(self):
         if not self._timed:
@@ -599,13 +654,19 @@ class TieredSumMerger:
         return out
 
     def release(self):
-        self.base = self.wire = self.ones = None
+        self.base = self.ones = self._args = self._flat = None
 
     def probe_buffer(self):
         return self.wire
 
     def pack(self, level):
         """-> (wire slice holding this rank's changes of the rows of tiers >= level of every table, per-table views)."""
+        if self.fused:
+            flat = self._flat[level]
+            if flat.numel():
+                with torch.cuda.device(flat.device):
+                    self.ops.tsum_pack(self._args[level], self._stride, flat, _lib.stream_ptr(flat.device))
+            return flat, None
         views, o = [], 0
         for i, t in enumerate(self.t):
             rows = self.plan.rows_ge[i][level]
@@ -617,11 +678,18 @@ class TieredSumMerger:
         return self.wire[:o], views
 
     def apply(self, level, views):
+        """Folds the all-reduced wire slice of pack(level) into the tables."""
+        self.n_merges[level] += 1
+        if self.fused:
+            flat = self._flat[level]
+            if flat.numel():
+                with torch.cuda.device(flat.device):
+                    self.ops.tsum_apply(self._args[level], self._stride, flat, _lib.stream_ptr(flat.device))
+            return
         for i, t in enumerate(self.t):
             rows = self.plan.rows_ge[i][level]
             if rows.numel():
                 self.ops.hot_apply(t, t, self.base[i], self.ones[i], rows, views[i])
-        self.n_merges[level] += 1
 
     def merge(self, level):
         t0 = self._mark()
@@ -686,15 +754,14 @@ def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, 
     n_chunks, plan = _tsum_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch)
     merger = TieredSumMerger([model.syn0, model.syn1neg], plan, comm, ops=ops)
     subs = chunk_plan(n_local, n_chunks * plan.sub, exact=True)
-    for ep in range(epochs):
-        for c, (b, e) in enumerate(subs):
-            if e > b:
-                model.train_pass(walks[b:e], None if lens is None else lens[b:e],
-                                 sentences_base=ep * n_walks_global + b * world, sentences_step=world,
-                                 sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset + b, splits="auto")
-            level = plan.level_due(c)
-            if level is not None:
-                merger.merge(level)
+    due = [plan.level_due(c) for c in range(len(subs))]
+    launch = model.span_trainer(walks, lens, sentences_total=total, sentences_step=world, splits="auto")
+    with torch.cuda.device(model.device):
+        for ep in range(epochs):
+            for c, (b, e) in enumerate(subs):
+                launch(b, e, ep * n_walks_global + b * world, ep * n_walks_global + shard_offset + b)
+                if due[c] is not None:
+                    merger.merge(due[c])
     return merger
 
 

@@ -363,6 +363,50 @@ def test_tiered_sum_merges_auc_within_band_simulated(torch_cuda, kind, G):
     assert abs(auc - auc_cpu) <= AUC_BAND, (kind, G, n_syncs, auc, auc_cpu)
 
 
+def test_fused_tiered_sum_kernels_equal_per_table_path(torch_cuda):
+    """n2v_tsum_pack / n2v_tsum_apply (all tables of a merge level in one launch) against the per-table restatement in
+    torch (tests/merge_reference.py), bit for bit, float32 and bfloat16 wires, every level of a three-tier plan."""
+    torch = torch_cuda
+    import numpy as np
+    from merge_reference import TorchMergeOps
+    from n2v_hip import sgns
+
+    class Doubling:                          # stands in for the all-reduce of two identical replicas
+        world, rank = 2, 0
+
+        def __init__(self, wire):
+            self.wire_dtype = wire
+
+        def all_reduce_async(self, t):
+            t.mul_(2)
+            return None
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n, stride = 1500, 128
+    counts = (np.random.default_rng(2).random(n) ** 6 * 40000 + 1).astype(np.int64)
+    plan = sgns.SumTierPlan(counts, 3.0e5, 2, 10, 5, torch.device("cuda"), theta=30.0, n_tiers=3, ratio=4)
+    assert all(0 < plan.rows_ge[i][2].numel() < plan.rows_ge[i][1].numel() < n for i in range(2))
+    for wire in (torch.float32, torch.bfloat16):
+        t0 = [torch.randn(n, stride, device="cuda", generator=g) for _ in range(2)]
+        a = [t.clone() for t in t0]
+        b = [t.clone() for t in t0]
+        fused = sgns.TieredSumMerger(a, plan, Doubling(wire))
+        plain = sgns.TieredSumMerger(b, plan, Doubling(wire), ops=TorchMergeOps())
+        assert fused.fused and not plain.fused
+        for step, level in enumerate([2, 2, 1, 2, 0, 1, 2, 0]):
+            d = [torch.randn(n, stride, device="cuda", generator=g) * 0.01 for _ in range(2)]
+            for x, y, dd in zip(a, b, d):
+                x += dd
+                y += dd
+            fused.merge(level)
+            plain.merge(level)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), (wire, step, level)
+        for i in range(2):
+            assert torch.equal(fused.base[i], plain.base[i]) and torch.equal(a[i], fused.base[i])
+        assert fused.n_merges == plain.n_merges == [2, 2, 4]
+
+
 def test_merge_kernels_equal_torch_restatement(torch_cuda):
     """n2v_merge_snapshot / _hot_apply / _flush (csrc/n2v_merge.hip) against tests/merge_reference.py, bit for bit,
     with float32 and bfloat16 wires, with and without a hot tier and a pending cold sum."""

@@ -167,6 +167,8 @@ def test_sum_tier_plan_and_schedule():
         per_merge = u / (4.0 ** t.double())
         assert bool((per_merge[u <= 500 * 64] <= 500 + 1e-9).all())
         assert plan.rows_ge[ti][0].numel() == 1000 and plan.rows_ge[ti][3].tolist() == torch.nonzero(t >= 3).flatten().tolist()
+    flat = sgns.SumTierPlan(np.full(1000, 100, dtype=np.int64), T, 8, 10, 5, torch.device("cpu"), theta=1e9)
+    assert flat.n_tiers == 1 and flat.sub == 1 and flat.level_due(0) == 0     # no hubs: one tier, no sub-intervals
     due = [plan.level_due(c) for c in range(128)]
     assert due[63] == 0 and due[127] == 0 and due[15] == 1 and due[31] == 1 and due[3] == 2 and due[0] == 3
     assert sum(1 for d in due[:64] if d is not None and d <= 1) == 4 and all(d is not None for d in due)   # ratio^(tiers-1) levels: every sub-interval merges the last tier
