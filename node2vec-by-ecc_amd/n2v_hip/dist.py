@@ -1,6 +1,7 @@
 """One process per GPU (BASELINE config C4): walks shard by start vertex with
 no collective, every rank trains a replica on its shard and the tables are merged over RCCL
-(`torch.distributed`, backend "nccl" = RCCL on ROCm) at the cadence of sgns.auto_syncs.
+(`torch.distributed`, backend "nccl" = RCCL on ROCm): by default pure sums at per-row cadences
+(sgns.TieredSumMerger), optionally weighted sums at the cadence of sgns.auto_syncs (merge="hot").
 
 Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
 The reference's only parallelism on this path is the same split of start nodes into contiguous
@@ -124,7 +125,7 @@ def global_counts(walks, n_words, ctx):
 def train_sharded(model, walks, lens, ctx, n_walks_global, shard_offset, epochs=1, syncs_per_epoch="auto",
                   merge="tsum", overlap=True, cold_delay=False):
     """sgns.train with this rank's communicator; afterwards every rank holds the merged tables.  Returns the
-    ReplicaMerger (its timers: bench.py's merge_seconds / overlap_fraction)."""
+    merger (its timers: bench.py's merge_seconds / overlap_fraction)."""
     assert model.device == ctx.device, "replica on %s but this rank owns %s" % (model.device, ctx.device)
     return sgns.train(model, walks, lens, epochs=epochs, comm=ctx.comm, n_walks_global=n_walks_global,
                       shard_offset=shard_offset, syncs_per_epoch=syncs_per_epoch, merge=merge, overlap=overlap,
