@@ -419,6 +419,9 @@ def main():
     # per-launch figures of THIS rank (rank 0): algorithmic bytes / mean launch duration
     walk_launch_s = sum(a.elapsed_time(b) for a, b, _, _ in marks) / 1e3 / K
     sgns_launch_s = sum(c.elapsed_time(d) for _, _, c, d in marks) / 1e3 / K
+    if world > 1:
+        # the kernel's share of the pass: the stream time between the marks minus what the merges took of it
+        sgns_launch_s = max(sgns_launch_s - merge_secs["merge"] / K, 1e-9)
     walk_bytes_launch = float(steps_done.item()) / K * WALK_BYTES_PER_STEP
     sgns_bytes_launch = float(model.pairs_trained()) / K * SGNS_BYTES_PER_PAIR_128 * stride_scale
     traffic, traffic_source = None, None
