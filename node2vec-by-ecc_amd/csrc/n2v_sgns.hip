@@ -23,6 +23,7 @@
 // gensim's Hogwild worker threads race with each other.  The path is HBM/L2 gather-scatter
 // bound; there is no dense contraction worth an MFMA.
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 
 #include "n2v_common.h"
@@ -56,6 +57,7 @@ struct SgnsArgs {
     unsigned long long* pair_count;
     int32_t lpad;
     int32_t splits;   // wavefronts per walk (>= 1): split s trains the centres [s*n/S, (s+1)*n/S) of the sentence
+    int32_t predraw;  // 1: all negatives of a centre are drawn by the lanes in parallel before its pairs (short launches)
 };
 
 // x -> x advanced by k steps of the sentence's 48-bit LCG (composition of the affine map by squaring)
@@ -315,6 +317,29 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
             Row<VPL> cd;  // kAtomic: this wave's accumulated change of the centre row
 #pragma unroll
             for (int v = 0; v < VPL; ++v) cd.v[v] = 0.f;
+            // A wave's pairs are a chain of dependent loads, and the look-up of the negatives (bucket index, then a
+            // bisect of the cumulative table) is two to three links of it per pair — visible even in full-size launches
+            // at 7 waves per SIMD.  With predraw the lanes make ALL draws of the centre at once — draw number d
+            // of the centre uses the walk's LCG advanced d times, exactly the state the pair-by-pair path reaches —
+            // and a pair fetches its targets from the lanes that hold them.
+            const int nd = (hi - lo - 1) * a.negative;
+            const bool pre = a.predraw && nd <= 128;
+            int32_t drawn0 = -1, drawn1 = -1;   // draws 0..63 and 64..127 of this centre, one per lane
+            if (pre) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int d = half * 64 + lane;
+                    int32_t t = -1;
+                    if (d < nd) {
+                        const uint64_t s = lcg_skip(lcg, (uint64_t)d);
+                        t = draw_target(a.cum_table, a.lut, a.lut_shift, (uint32_t)((s >> 16) % 2147483647ULL));
+                        if (t == ci) t = -1;  // `if target_index == word_index: continue`
+                    }
+                    if (half == 0) drawn0 = t;
+                    else drawn1 = t;
+                }
+            }
+            int pidx = 0;  // number of this pair among the centre's pairs
             for (int j = lo; j < hi; ++j) {
                 if (j == i) continue;
                 const int32_t xj = __builtin_amdgcn_readfirstlane(sent[j]);
@@ -326,7 +351,12 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
                 for (int t0 = 0; t0 < a.negative + 1; t0 += 8) {
                     // lane k (k < 8) draws the target of slot k of this group
                     int32_t my_t = -1;
-                    {
+                    if (pre) {   // negative <= 7: one group, lane k in [1, negative] holds target k
+                        const int d = min(max(pidx * a.negative + lane - 1, 0), 127);
+                        const int v0 = __builtin_amdgcn_ds_bpermute((d & 63) << 2, drawn0);
+                        const int v1 = __builtin_amdgcn_ds_bpermute((d & 63) << 2, drawn1);
+                        if (lane >= 1 && lane <= a.negative) my_t = d < 64 ? v0 : v1;
+                    } else {
                         const int tk = t0 + lane;  // target number: 0 = positive, d >= 1 = d-th negative
                         if (lane < 8 && tk >= 1 && tk <= a.negative) {
                             uint64_t s = lcg;  // state of the first draw of this group
@@ -406,6 +436,7 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
                     for (int v = 0; v < VPL; ++v) h.v[v] += work.v[v];
                     store_row<VPL, MODE>(a.syn0, xj, a.row_stride, lane, h);
                 }
+                ++pidx;
                 ++pairs_done;
             }
             if constexpr (MODE == kAtomic) add_row<VPL>(a.syn1neg, ci, a.row_stride, lane, cd);
@@ -647,6 +678,19 @@ extern "C" int n2v_sgns_init(float* syn0, float* syn1neg, int64_t n_words, int32
     return n2v::check_launch("n2v_sgns_init");
 }
 
+namespace {
+// predraw (parallel draws of a centre's negatives): on whenever negative <= 7 (one target group).  Measured on C3's
+// walks: full-size launches 7.98e8 -> 8.85e8 pairs/s, one wavefront per walk (latency-bound) 3.49 -> 2.67 us per pair,
+// the 83-walk launches of the tiered merges 145 -> 128 us.  N2V_SGNS_PREDRAW=0 switches it off (A/B timing, and the
+// test that both paths train the same bits).
+int predraw_mode(int walk_splits, int negative) {
+    (void)walk_splits;
+    if (negative < 1 || negative > 7) return 0;
+    const char* e = getenv("N2V_SGNS_PREDRAW");
+    return (e && e[0] == '0') ? 0 : 1;
+}
+}  // namespace
+
 extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
                               float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
                               int32_t window, int32_t negative, const uint32_t* sample_int,
@@ -688,6 +732,7 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     a.seed = seed; a.walk_id_base = walk_id_base; a.pair_count = pair_count;
     a.lpad = (walk_stride + 63) & ~63;
     a.splits = walk_splits;
+    a.predraw = predraw_mode(walk_splits, negative);
     const size_t shmem = (size_t)4 * a.lpad * sizeof(int32_t);
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks * walk_splits + 3) / 4;

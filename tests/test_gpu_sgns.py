@@ -160,6 +160,38 @@ def test_walk_splits_train_the_same_pairs_and_stay_in_the_band(torch_cuda):
         ref.train_pass(corpus.walks, corpus.lens, sentences_base=0, sentences_total=1, walk_id_base=0, splits=81)
 
 
+def test_parallel_negative_draws_train_the_same_bits(torch_cuda, monkeypatch):
+    """The kernel draws all negatives of a centre in parallel (draw d of the centre = the walk's LCG advanced d times)
+    instead of pair by pair (N2V_SGNS_PREDRAW=0).  One walk on one wavefront is a sequential, deterministic
+    run: both paths must leave bit-identical tables, for every row-sharing mode; on a full corpus (racing wavefronts)
+    the pair count is identical."""
+    torch = torch_cuda
+    from n2v_hip import sgns
+    g, corpus, counts, te_d, neg_d, rounds, auc_cpu = _band_case("uniform")
+    for mode in ("atomic", "agent", "plain"):
+        tables = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("N2V_SGNS_PREDRAW", flag)
+            m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1, update_mode=mode)
+            m.build_vocab(counts=counts)
+            for w in (0, 7, 1234):                      # three single-walk launches, one wavefront each
+                m.train_pass(corpus.walks[w:w + 1], corpus.lens[w:w + 1], sentences_base=w,
+                             sentences_total=corpus.walks.shape[0], walk_id_base=w, max_blocks=1)
+            torch.cuda.synchronize()
+            tables.append((m.syn0.clone(), m.syn1neg.clone(), m.pairs_trained()))
+        assert tables[0][2] == tables[1][2] > 1000
+        assert torch.equal(tables[0][0], tables[1][0]) and torch.equal(tables[0][1], tables[1][1]), mode
+    counts_pairs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("N2V_SGNS_PREDRAW", flag)
+        m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1)
+        m.build_vocab(counts=counts)
+        m.train_pass(corpus.walks, corpus.lens, sentences_base=0, sentences_total=corpus.walks.shape[0], walk_id_base=0,
+                     splits=8)
+        counts_pairs.append(m.pairs_trained())
+    assert counts_pairs[0] == counts_pairs[1]
+
+
 def test_untouched_rows_stay_put(torch_cuda):
     torch = torch_cuda
     from n2v_hip import sgns

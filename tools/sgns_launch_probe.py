@@ -17,7 +17,9 @@ corpus = g.simulate_walks(2, 80)
 m = sgns.SgnsModel(cg.n_nodes, dim=128, window=10, negative=5, seed=1, update_mode="agent")
 m.build_vocab(corpus.walks)
 W = corpus.walks.shape[0]
-for size, splits in [(sz, sp) for sz in (83, 334, 1335, 2298, 5342, 21368, 200000) for sp in (1, "auto")]:
+SIZES = [int(x) for x in os.environ.get("SIZES", "83,334,1335,2298,5342,21368,200000").split(",")]
+print("N2V_SGNS_PREDRAW =", os.environ.get("N2V_SGNS_PREDRAW"), flush=True)
+for size, splits in [(sz, sp) for sz in SIZES for sp in (1, "auto")]:
     n_launch = max(4, min(200, 400000 // size))
     m.pair_count.zero_()
     torch.cuda.synchronize()
