@@ -11,7 +11,7 @@ cg, info = synth.make_config_graph("C3")
 g = node2vec.Graph.from_csr(cg, 0.25, 4.0, rng="philox", seed=1)
 g.preprocess_transition_probs()
 corpus = g.simulate_walks(2, 80)
-m = sgns.SgnsModel(cg.n_nodes, dim=128, window=10, negative=5, seed=1)
+m = sgns.SgnsModel(cg.n_nodes, dim=128, window=10, negative=5, seed=1, update_mode=os.environ.get("MODE", "agent"))   # bench's C3 mode
 m.build_vocab(corpus.walks)
 W = corpus.walks.shape[0]
 
@@ -29,10 +29,10 @@ def run(n_walks, mb, reps=1):
 
 
 run(W, 0)
-for mb in (1024, 2048, 3072, 4096, 6144):
+for mb in [int(x) for x in os.environ.get("GRIDS", "1024,2048,3072,4096,6144").split(",")]:
     dt, rate = run(W, mb)
     print("full pass %7d walks  max_blocks %5d: %.3f s  %.3e pairs/s" % (W, mb, dt, rate), flush=True)
-for n in (5356, 10700, 21400):
+for n in ([] if os.environ.get("FULL_ONLY") else [5356, 10700, 21400]):
     for mb in (2048, 3072, 4096):
         dt, rate = run(n, mb, reps=40)
         print("interval  %7d walks  max_blocks %5d: %.2f ms per launch  %.3e pairs/s" % (n, mb, dt / 40 * 1e3, rate), flush=True)
