@@ -313,7 +313,7 @@ def main():
     def sgns_step(step_no, timed=False):
         mg = sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
                         syncs_per_epoch=syncs if args.merge != "tsum" else "auto", merge=args.merge,
-                        overlap=not args.no_overlap)
+                        overlap=not args.no_overlap, timers=timed)
         if timed and mg is not None:
             if mergers:
                 mergers[-1].release()       # keep the timers, not 2.5 GB of snapshots per timed step

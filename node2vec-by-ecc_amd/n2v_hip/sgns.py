@@ -612,7 +612,7 @@ class TieredSumMerger:
     tiers >= level since THEIR last merge, all-reduces them (sum) and folds the sum in — every change is applied exactly
     once with weight 1 on every rank; only the time at which the other ranks see it depends on the row's tier."""
 
-    def __init__(self, tables, plan, comm, ops=None):
+    def __init__(self, tables, plan, comm, ops=None, timed=False):
         self.t, self.plan, self.comm = list(tables), plan, comm
         self.ops = ops if ops is not None else HipMergeOps()
         dev = self.t[0].device
@@ -624,7 +624,8 @@ class TieredSumMerger:
         self.wire = torch.zeros((sum(int(t.shape[0]) for t in self.t), stride), dtype=wire, device=dev)
         self.n_merges = [0] * plan.n_tiers
         self._ev = []
-        self._timed = dev.type == "cuda"
+        # timers are opt-in (bench.py): four events per merge, ~15 000 merges per pass at 8 GPUs
+        self._timed = bool(timed) and dev.type == "cuda"
         # all tables of a level in one launch per step (n2v_tsum_pack / n2v_tsum_apply), arguments prepared once:
         # the hub tiers' merges are launch- and host-bound
         self.fused = hasattr(self.ops, "tsum_pack") and dev.type == "cuda"
@@ -743,7 +744,7 @@ def _tsum_setup(model, L, n_walks_global, world, syncs_per_epoch):
     return n_chunks, plan
 
 
-def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops):
+def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops, timers=False):
     """merge="tsum": pure sums at per-row cadences (SumTierPlan).  The pass is cut into base intervals x sub-intervals;
     after every sub-interval the tiers that are due are merged.  Meets the AUC band at every graph size in simulation
     (DESIGN.md 6), but the launches between two hub-tier merges are short (n_local / (n_chunks * 64) walks): the
@@ -752,7 +753,7 @@ def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, 
     world = comm.world
     total = epochs * n_walks_global
     n_chunks, plan = _tsum_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch)
-    merger = TieredSumMerger([model.syn0, model.syn1neg], plan, comm, ops=ops)
+    merger = TieredSumMerger([model.syn0, model.syn1neg], plan, comm, ops=ops, timed=timers)
     subs = chunk_plan(n_local, n_chunks * plan.sub, exact=True)
     due = [plan.level_due(c) for c in range(len(subs))]
     launch = model.span_trainer(walks, lens, sentences_total=total, sentences_step=world, splits="auto")
@@ -766,12 +767,13 @@ def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, 
 
 
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
-          merge="tsum", overlap=True, cold_delay=False, ops=None):
+          merge="tsum", overlap=True, cold_delay=False, ops=None, timers=False):
     """Train `epochs` passes over this rank's walks.  With a communicator the replicas are merged: merge="tsum"
     (default) by pure sums at per-row cadences (TieredSumMerger) — the scheme that stays inside the AUC band at
     every graph size measured —, merge="hot" by per-row-weighted sums at `syncs_per_epoch` merges per pass
     (ReplicaMerger; several times faster at 8 GPUs, inside the band on the small probe graphs, 0.003-0.006 off at
-    131k nodes).  Returns the merger (None on one GPU) so that the caller can read its timers."""
+    131k nodes).  Returns the merger (None on one GPU); timers=True makes the tiered-sum merger record the stream
+    time of its merges (`seconds()`; the weighted merger always does — it merges a hundred times per pass, not 15 000)."""
     n_local = int(walks.shape[0])
     if n_walks_global is None:
         n_walks_global = n_local
@@ -783,7 +785,7 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
                              sentences_total=total, walk_id_base=ep * n_walks_global + shard_offset)
         return None
     if merge == "tsum":
-        return _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops)
+        return _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops, timers)
     n_chunks, plan = _merge_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch, merge, cold_delay)
     merger = ReplicaMerger([model.syn0, model.syn1neg], plan, comm, overlap=overlap, ops=ops)
     chunks = chunk_plan(n_local, n_chunks, exact=True)

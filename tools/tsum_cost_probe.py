@@ -57,7 +57,7 @@ for name, ops in [VARIANTS[v] for v in os.environ.get("VARIANTS", "fused,per_tab
         prof.enable()
     t0 = time.perf_counter()
     a.record()
-    mg = sgns.train(m, walks, lens, epochs=1, comm=NoWire(), n_walks_global=n_global, shard_offset=0, merge="tsum", ops=ops)
+    mg = sgns.train(m, walks, lens, epochs=1, comm=NoWire(), n_walks_global=n_global, shard_offset=0, merge="tsum", ops=ops, timers=bool(os.environ.get("TIMERS", "1") == "1"))
     t_host = time.perf_counter() - t0
     if prof is not None:
         prof.disable()
