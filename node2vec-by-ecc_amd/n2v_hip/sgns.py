@@ -619,7 +619,6 @@ class TieredSumMerger:
         wire = getattr(comm, "wire_dtype", None) or torch.float32
         self.base = [t.clone() for t in self.t]
         stride = int(self.t[0].shape[1])
-        self.ones = [torch.ones(int(t.shape[0]), dtype=torch.float32, device=dev) for t in self.t]
         # ONE wire buffer for all tables (their due rows back to back): one collective per merge
         self.wire = torch.zeros((sum(int(t.shape[0]) for t in self.t), stride), dtype=wire, device=dev)
         self.n_merges = [0] * plan.n_tiers
@@ -629,6 +628,8 @@ class TieredSumMerger:
         # all tables of a level in one launch per step (n2v_tsum_pack / n2v_tsum_apply), arguments prepared once:
         # the hub tiers' merges are launch- and host-bound
         self.fused = hasattr(self.ops, "tsum_pack") and dev.type == "cuda"
+        # the per-table path reuses the weighted merges' fold-in kernel with weight 1 on every row
+        self.ones = None if self.fused else [torch.ones(int(t.shape[0]), dtype=torch.float32, device=dev) for t in self.t]
         if self.fused:
             self._stride = stride
             self._args, self._flat = [], []
