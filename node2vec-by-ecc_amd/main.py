@@ -47,6 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"],
                     help="numpy: consume numpy's global MT19937 stream like the reference; philox: in-kernel RNG")
     ap.add_argument("--seed", type=int, default=1, help="seed of the philox walk RNG and of the SGNS trainer")
+    ap.add_argument("--merge", default="tsum", choices=["tsum", "hot"],
+                    help="more than one GPU: how the ranks' replicas are merged (n2v_hip/sgns.py: tiered pure sums, or "
+                         "weighted sums — faster, AUC band on small graphs only)")
     return ap.parse_args(argv)
 
 
@@ -121,7 +124,8 @@ def main(args_):
     # embedding (BASELINE config C4)
     assert G._engine.device == ctx.device, (G._engine.device, ctx.device)
     walks = G.simulate_walks_shard(args.num_walks, args.walk_length, ctx.rank, ctx.world)
-    emb = learn_embeddings(walks, ctx=ctx, n_starts=G._csr.n_nodes, num_walks=args.num_walks)
+    emb = learn_embeddings(walks, ctx=ctx, n_starts=G._csr.n_nodes, num_walks=args.num_walks,
+                           merge=getattr(args, "merge", "tsum"))
     ctx.barrier()
     return emb
 
