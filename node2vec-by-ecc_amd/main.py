@@ -48,7 +48,7 @@ def parse_args(argv=None):
                     help="numpy: consume numpy's global MT19937 stream like the reference; philox: in-kernel RNG")
     ap.add_argument("--seed", type=int, default=1, help="seed of the philox walk RNG and of the SGNS trainer")
     ap.add_argument("--merge", default="tsum", choices=["tsum", "hot"],
-                    help="more than one GPU: how the ranks' replicas are merged (n2v_hip/sgns.py: tiered pure sums, or "
+                    help="more than one GPU: how the ranks' replicas are merged (n2v_hip/merge.py: tiered pure sums, or "
                          "weighted sums — faster, AUC band on small graphs only)")
     return ap.parse_args(argv)
 

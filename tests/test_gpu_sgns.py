@@ -315,7 +315,7 @@ def _band_case(kind):
     from n2v_hip import linkpred
     from oracle import c_oracle, sgns_oracle
     g, te, neg = _auc_setup() if kind == "uniform" else _hub_setup()
-    rounds = 10     # as the probes behind the merge constants (n2v_hip/sgns.py); the hub comparator takes ~3 minutes once
+    rounds = 10     # as the probes behind the merge constants (n2v_hip/merge.py); the hub comparator takes ~3 minutes once
     Gr = node2vec.Graph.from_csr(g, 1.0, 1.0, rng="philox", seed=1)
     Gr.preprocess_transition_probs()
     corpus = Gr.simulate_walks(rounds, 80)
@@ -332,7 +332,7 @@ def _band_case(kind):
 
 
 _EDGE = pytest.mark.xfail(strict=False, reason="four replicas on the uniform graph: +0.0019 measured, 0.0001 inside the band — "
-                                                 "the one case of the merge scheme without any slack (n2v_hip/sgns.py)")
+                                                 "the one case of the merge scheme without any slack (n2v_hip/merge.py)")
 
 
 @pytest.mark.parametrize("kind,G", [("uniform", 1), ("uniform", 2), pytest.param("uniform", 4, marks=_EDGE), ("uniform", 8),
