@@ -9,9 +9,9 @@ reference tree; the statistics below restate its public ``scale_vocab`` / ``make
 (negative=5, alpha=0.025, min_alpha=1e-4, sample=1e-3, ns exponent 0.75).
 
 Multi-GPU: every rank trains a full replica on its shard of the walks
-(shard = contiguous start positions, as for the walk itself) and the two tables are
-all-reduced over RCCL at sync points inside the epoch and at its end; the learning-rate
-schedule is driven by the GLOBAL sentence count.
+(shard = contiguous start positions, as for the walk itself) and the replicas are merged
+over RCCL inside the pass and at its end (the schemes: n2v_hip/merge.py; `train` below
+drives them); the learning-rate schedule is driven by the GLOBAL sentence count.
 """
 import numpy as np
 import torch
