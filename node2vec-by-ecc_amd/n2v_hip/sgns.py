@@ -13,6 +13,8 @@ Multi-GPU: every rank trains a full replica on its shard of the
 over RCCL inside the pass and at its end (the schemes: n2v_hip/merge.py; `train` below
 drives them); the learning-rate schedule is driven by the GLOBAL sentence count.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -241,7 +243,8 @@ def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, 
     subs = chunk_plan(n_local, n_chunks * plan.sub, exact=True)
     due = [plan.level_due(c) for c in range(len(subs))]
     launch = model.span_trainer(walks, lens, sentences_total=total, sentences_step=world, splits="auto")
-    with torch.cuda.device(model.device):
+    # (the host-logic tests drive this loop with a stand-in model on CPU tensors)
+    with (torch.cuda.device(model.device) if model.device.type == "cuda" else contextlib.nullcontext()):
         for ep in range(epochs):
             for c, (b, e) in enumerate(subs):
                 launch(b, e, ep * n_walks_global + b * world, ep * n_walks_global + shard_offset + b)

@@ -306,6 +306,47 @@ other = t.clone(); dist.broadcast(other, src=0)
 assert torch.equal(other, t) and mg.n_merges == [K // 2, K // 2]
 b, e = sgns.shard_bounds(101, 2, rank)
 tot = torch.tensor([e - b]); dist.all_reduce(tot); assert int(tot) == 101
+# the whole driver (sgns.train, merge="tsum") with UNEVEN shards and a stand-in model whose "training" of a walk
+# adds 1 to the row of each of its tokens: same number of collectives on both ranks (no deadlock), every walk applied
+# exactly once, identical tables at the end
+import numpy as np
+class StandIn:
+    n_words, window, negative, device = 40, 10, 5, torch.device("cpu")
+    def __init__(self):
+        self.counts = np.r_[np.full(4, 4000), np.full(36, 50)].astype(np.int64)      # four hub rows -> more than one tier
+        self.syn0 = torch.zeros(40, 4); self.syn1neg = torch.zeros(40, 4)
+        self.trained = []
+    def span_trainer(self, walks, lens, sentences_total, sentences_step, splits="auto"):
+        def launch(b, e, sentences_base, walk_id_base):
+            for w in range(b, e):
+                self.trained.append(walk_id_base + (w - b))
+                for tok in walks[w].tolist():
+                    self.syn0[tok] += 1.0; self.syn1neg[tok] -= 0.5
+        return launch
+    def train_pass(self, walks, lens, sentences_base, sentences_total, walk_id_base, sentences_step=1, max_blocks=0, splits=1):
+        self.span_trainer(walks, lens, sentences_total, sentences_step)(0, int(walks.shape[0]), sentences_base, walk_id_base)
+g = torch.Generator().manual_seed(9)
+n_global = 61
+all_walks = torch.randint(0, 40, (n_global, 8), generator=g, dtype=torch.int32)
+b, e = sgns.shard_bounds(n_global, 2, rank)                                           # 31 and 30 walks
+m = StandIn()
+mg = sgns.train(m, all_walks[b:e].contiguous(), None, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=b,
+                merge="tsum", ops=TorchMergeOps())
+assert mg.plan.n_tiers >= 2 and sum(mg.n_merges) >= mg.plan.sub, (mg.plan.n_tiers, mg.n_merges)
+assert m.trained == list(range(b, e))                                                # every local walk once, in order
+want = torch.zeros(40, 4)
+for tok in all_walks.reshape(-1).tolist():
+    want[tok] += 1.0
+assert torch.equal(m.syn0, want) and torch.equal(m.syn1neg, -0.5 * want), (m.syn0[:5], want[:5])
+other = m.syn0.clone(); dist.broadcast(other, src=0); assert torch.equal(other, m.syn0)
+# the weighted merges through the same driver: linear in the changes, weight w[row] on the summed change
+m2 = StandIn()
+mg2 = sgns.train(m2, all_walks[b:e].contiguous(), None, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=b,
+                 merge="hot", syncs_per_epoch=5, ops=TorchMergeOps())
+assert m2.trained == list(range(b, e)) and mg2.n_merges == 5
+assert torch.allclose(m2.syn0, mg2.plan.w[0][:, None] * want, atol=1e-4), (m2.syn0[:5], want[:5], mg2.plan.w[0][:5])
+assert torch.allclose(m2.syn1neg, -0.5 * mg2.plan.w[1][:, None] * want, atol=1e-4)
+other = m2.syn0.clone(); dist.broadcast(other, src=0); assert torch.equal(other, m2.syn0)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
