@@ -253,6 +253,26 @@ def main():
     dump_case("er600_directed", de2, (rs.random_sample(1200) + 0.5).tolist(), True, 0.25, 4.0,
               [{"seed": 123, "r": 2, "L": 30}, {"seed": 3, "r": 1, "L": 80}])
 
+    # directed hub with 520 out-neighbours (> 512: the wave-per-table builder's in-place path and the on-the-fly
+    # kernel's global scratch) reached over five in-edges, so only five tables are that large; cycles through the hub
+    he, hw = [], []
+    for t in range(1, 521):
+        he.append((0, t)); hw.append(0.25 + (t * 37 % 11) / 4.0)
+    for s_ in range(521, 526):
+        he.append((s_, 0)); hw.append(1.0 + 0.5 * (s_ - 521))
+    for t in range(1, 521):
+        if t % 7 == 0:
+            he.append((t, 521 + t % 5)); hw.append(0.75)
+        if t % 13 == 0:
+            he.append((t, 0)); hw.append(2.0)                      # straight back to the hub (p branch)
+        if t % 5 == 0:
+            he.append((t, (t * 3) % 520 + 1)); hw.append(1.5)      # target -> target: common-neighbour branch
+    for s_ in range(521, 526):
+        he.append((s_, (s_ * 17) % 520 + 1)); hw.append(0.6)
+    dump_case("hub520_directed", he, hw, True, 0.25, 4.0,
+              [{"seed": 123, "r": 2, "L": 40}, {"seed": 4, "r": 1, "L": 80, "nodes": [521, 0, 7, 522, 13, 525]},
+               {"seed": 123, "r": 1, "L": 20, "on_the_fly": True}])
+
 
 if __name__ == "__main__":
     main()
