@@ -113,6 +113,11 @@ int n2v_build_edge_recs(int64_t n_nodes, int64_t nnz, const int64_t* row_ptr, co
 
 #define N2V_RNG_UNIFORMS 0 /* parity mode: two fp64 uniforms per step read from `uniforms` */
 #define N2V_RNG_PHILOX 1   /* throughput mode: Philox4x32-10(seed; global walk index, step) */
+#define N2V_RNG_UNIFORMS_TILED 2 /* parity mode, `uniforms` in the layout of n2v_mt19937_fill_tiled (n2v_walk_fat only):
+                                    a walk whose LINEAR offset is o = s * 2(L-1) (s = its rank among the walks that draw)
+                                    reads step t (1-based) at uniforms[2 * (((s >> 6) * (L-1) + (t-1)) * 64 + (s & 63))], [+1]
+                                    — the 64 walks of a wavefront read 1 KiB of consecutive bytes per step.  Only for
+                                    calls in which no walk can end early (every offset is a multiple of 2(L-1)).      */
 
 /* Walks for start positions [pos_begin, pos_begin+pos_count) of `starts` (dense ids in
  * list(G.nodes()) order) and rounds [round_begin, round_begin+round_count).
@@ -149,12 +154,16 @@ int n2v_build_fat_slots(int64_t n_tables, const int64_t* tab_off, const int32_t*
                         n2v_fat_slot* fat, void* stream);
 
 /* n2v_walk over fat tables: identical output.  node_fat: fat node tables (slot k of node v at
- * row_ptr[v]+k); fat: the array the records' table indices address.                         */
+ * row_ptr[v]+k); fat: the array the records' table indices address.  rng_mode may also be
+ * N2V_RNG_UNIFORMS_TILED (walk_uoff still holds the LINEAR offsets).
+ * uoff_round_stride > 0: every round consumes that many uniforms and walk_uoff has pos_count entries, the offsets
+ * inside a round: local walk (round_local, pos_local) reads at walk_uoff[pos_local] + round_local * uoff_round_stride
+ * (no per-walk array of round_count * pos_count offsets); 0: walk_uoff[lw] as in n2v_walk.                        */
 int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat, const n2v_fat_slot* fat,
                  const int32_t* starts, int64_t n_starts, int64_t pos_begin, int64_t pos_count,
                  int64_t round_begin, int64_t round_count, int32_t walk_length, int32_t rng_mode,
-                 const double* uniforms, const int64_t* walk_uoff, uint64_t seed, int32_t* walks,
-                 int32_t* lens, void* stream);
+                 const double* uniforms, const int64_t* walk_uoff, int64_t uoff_round_stride, uint64_t seed,
+                 int32_t* walks, int32_t* lens, void* stream);
 
 /* numpy's legacy MT19937 stream (np.random.rand(), src/node2vec.py:277-278) on the device.
  * n2v_mt19937_jump_host: pure host arithmetic.  key_host: the 624 state words of
@@ -178,6 +187,14 @@ int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, const uint32_t*
                             void* stream);
 int n2v_mt19937_fill(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
                      int64_t n_doubles, double* out, uint32_t* final_state, void* stream);
+/* The same doubles, regrouped for the walk kernel's coalesced reads (N2V_RNG_UNIFORMS_TILED): the stream is cut into
+ * segments of 2*pairs_per_walk doubles (one walk of pairs_per_walk = L-1 steps each: the two np.random.rand() of
+ * src/node2vec.py:277-278 per step); segment s, pair t, component c (double 2*pairs_per_walk*s + 2t + c of the
+ * stream) is written to out[2 * (((s >> 6) * pairs_per_walk + t) * 64 + (s & 63)) + c].  out must hold
+ * ceil(S / 64) * 64 * 2 * pairs_per_walk doubles for S = ceil(n_doubles / (2*pairs_per_walk)) segments (a last partial
+ * group of 64 leaves gaps that are never read).  Same stream, same final_state as n2v_mt19937_fill.             */
+int n2v_mt19937_fill_tiled(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
+                           int64_t n_doubles, int32_t pairs_per_walk, double* out, uint32_t* final_state, void* stream);
 
 /* simulate_walks_on_the_fly / node2vec_walk_on_the_fly (src/node2vec.py:13-53,97-111): the
  * same walk with the (prev, cur) table rebuilt at every step instead of read from the edge

@@ -17,6 +17,7 @@
 // numpy's own algorithm — lazy block twist, tempering, (a>>5, b>>6) -> double — one wavefront
 // per stream with the 624-word window in LDS, and hands back the final (key, pos) so the
 // caller can leave numpy's global state exactly where the reference would have left it.
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -237,18 +238,97 @@ __device__ __forceinline__ uint32_t twist_word(const uint32_t* mt, int i) {
     return mt[im] ^ (y >> 1) ^ ((y & 1u) ? kMatrixA : 0u);
 }
 
+// Where double d of the stream goes.  Linear: out[d].  Tiled (n2v_mt19937_fill_tiled): the stream is cut into
+// segments of dpw = 2 * pairs doubles (one walk each); segment s, pair t, component c lands at
+// out[2 * (((s >> 6) * pairs + t) * 64 + (s & 63)) + c], so that step t of 64 consecutive walks is 1 KiB of
+// consecutive bytes.  A stream starts at segment s0, remainder r0 (one 64-bit division per stream); inside the stream
+// the split of r0 + (d - d0) < 2^32 uses a host-made reciprocal with one correction step.
+struct TileMap {
+    uint32_t dpw, pairs, recip;   // recip = floor(2^32 / dpw)
+};
+
+template <bool TILED>
+struct OutMap {
+    double* out;
+    int64_t d0, s0;
+    uint32_t r0;
+    TileMap m;
+    __device__ __forceinline__ void put(int64_t d, double v) const {
+        if (!TILED) {
+            out[d] = v;
+            return;
+        }
+        const uint32_t y = r0 + (uint32_t)(d - d0);
+        uint32_t qd = __umulhi(y, m.recip);
+        uint32_t rem = y - qd * m.dpw;
+        if (rem >= m.dpw) { rem -= m.dpw; ++qd; }
+        const int64_t s = s0 + qd;
+        out[2 * (((s >> 6) * m.pairs + (rem >> 1)) * 64 + (s & 63)) + (rem & 1u)] = v;
+    }
+};
+
+// MODE 0: linear output.  MODE 1: tiled, every double written where it lands (16-B pieces of lines: 3x the time of the
+// linear fill on C3).  MODE 2: tiled through an LDS ring: a wavefront's stream is consumed in groups of four walk
+// segments (8 * pairs doubles); the four segments' pairs of one step are 64 contiguous, 64-B aligned bytes of the tiled
+// layout, so a finished group leaves as whole lines (lane e writes pair e >> 2 of segment e & 3).  Only the ragged ends
+// of a stream (its first and last partial group) go through MODE 1's element-wise path.
+constexpr int kFillLdsHead = (kN + 16 + 4) * 4;   // 2576 B = 161 * 16
+
+template <int MODE>
 __global__ void __launch_bounds__(64)
 mt_fill_kernel(const uint32_t* __restrict__ states, int pos0, int64_t words_per_stream, int64_t total_words,
-               double* __restrict__ out, uint32_t* __restrict__ final_state) {
-    __shared__ uint32_t mt[kN + 16];
-    __shared__ uint32_t carry_word;
+               double* __restrict__ out_ptr, uint32_t* __restrict__ final_state, TileMap tm, int ring_log2) {
+    // all LDS in the dynamic region, carved at multiples of 16 B (a static in front would shift the ring off the 16-B
+    // alignment its double2 reads need): window [640 words], the carried word, then MODE 2's ring of 2^ring_log2 doubles
+    extern __shared__ __attribute__((aligned(16))) unsigned char fill_smem[];
+    uint32_t* mt = reinterpret_cast<uint32_t*>(fill_smem);
+    uint32_t& carry_word = mt[kN + 16];
+    double* ring = reinterpret_cast<double*>(fill_smem + kFillLdsHead);
     const int lane = threadIdx.x;
     const int64_t k = blockIdx.x;
+    OutMap<MODE != 0> out{out_ptr, 0, 0, 0u, tm};
+    const int64_t d_begin = (k * words_per_stream) >> 1;   // words_per_stream is even: no double straddles two streams
+    if (MODE != 0) {
+        out.d0 = d_begin;
+        out.s0 = out.d0 / tm.dpw;
+        out.r0 = (uint32_t)(out.d0 - out.s0 * tm.dpw);
+    }
+    const uint32_t mask = MODE == 2 ? (1u << ring_log2) - 1u : 0u;
+    const int64_t G = 4 * (int64_t)tm.dpw;     // doubles per group of four segments
+    int64_t flushed = d_begin;                 // MODE 2: first double not yet written to global memory
     for (int i = lane; i < kN; i += 64) mt[i] = states[k * kN + i];
     lds_order();
     int pos = pos0;
     int64_t produced = k * words_per_stream;
     const int64_t w_end = min(total_words, produced + words_per_stream);
+
+    auto emit = [&](int64_t d, double v) {
+        if (MODE == 2) ring[(uint32_t)d & mask] = v;
+        else out.put(d, v);
+    };
+    // MODE 2: write [flushed, upto) from the ring; whole groups as 64-B lines, the rest double by double
+    auto flush = [&](int64_t upto) {
+        while (flushed < upto) {
+            const int64_t gi = flushed / G;
+            const int64_t gend = (gi + 1) * G;
+            if (flushed == gi * G && gend <= upto) {
+                const int64_t s4 = 4 * gi;                                 // first segment of the group
+                double* base = out_ptr + 2 * (((s4 >> 6) * tm.pairs) * 64 + (s4 & 63));
+                for (uint32_t e = lane; e < 4 * tm.pairs; e += 64) {
+                    const uint32_t j = e & 3u, t = e >> 2;
+                    const uint32_t src = ((uint32_t)flushed + j * tm.dpw + 2 * t) & mask;   // even: the pair never wraps
+                    const double2 v = *reinterpret_cast<const double2*>(&ring[src]);
+                    *reinterpret_cast<double2*>(base + 2 * ((int64_t)t * 64 + j)) = v;
+                }
+                flushed = gend;
+            } else {
+                const int64_t stop = min(gend, upto);
+                for (int64_t d = flushed + lane; d < stop; d += 64) out.put(d, ring[(uint32_t)d & mask]);
+                flushed = stop;
+            }
+        }
+    };
+
     while (produced < w_end) {
         if (pos >= kN) {
             // numpy's block twist, in place.  Word i needs old i, i+1 and (i < 227 ? old i+397
@@ -279,13 +359,13 @@ mt_fill_kernel(const uint32_t* __restrict__ states, int pos0, int64_t words_per_
         const int odd = (int)(produced & 1);
         if (odd && lane == 0) {
             const uint32_t a = carry_word >> 5, b = temper(mt[pos]) >> 6;
-            out[(produced - 1) >> 1] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+            emit((produced - 1) >> 1, ((double)a * 67108864.0 + (double)b) / 9007199254740992.0);
         }
         for (int ia = odd + 2 * lane; ia < take; ia += 128) {
             const uint32_t ya = temper(mt[pos + ia]);
             if (ia + 1 < take) {
                 const uint32_t a = ya >> 5, b = temper(mt[pos + ia + 1]) >> 6;
-                out[(produced + ia) >> 1] = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+                emit((produced + ia) >> 1, ((double)a * 67108864.0 + (double)b) / 9007199254740992.0);
             } else {
                 carry_word = ya;  // its partner is word 0 of the next block
             }
@@ -293,6 +373,14 @@ mt_fill_kernel(const uint32_t* __restrict__ states, int pos0, int64_t words_per_
         lds_order();
         pos += take;
         produced += take;
+        if (MODE == 2) {
+            // complete doubles so far: [d_begin, produced >> 1); keep less than one group in the ring
+            const int64_t done = produced >> 1;
+            if (done - flushed >= G || produced >= w_end) {
+                flush(produced >= w_end ? done : (done / G) * G);
+                lds_order();
+            }
+        }
     }
     if (w_end == total_words && final_state && k * words_per_stream < total_words) {
         for (int i = lane; i < kN; i += 64) final_state[i] = mt[i];
@@ -457,15 +545,50 @@ extern "C" int n2v_mt19937_jump_device(uint32_t* states, int32_t n_streams, cons
     return n2v::check_launch("n2v_mt19937_jump_device");
 }
 
-extern "C" int n2v_mt19937_fill(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
-                                int64_t n_doubles, double* out, uint32_t* final_state, void* stream) {
+static int fill_common(const char* what, const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
+                       int64_t n_doubles, int32_t pairs_per_walk, double* out, uint32_t* final_state, void* stream) {
     if (!states || n_streams < 1 || pos < 0 || pos > kN || words_per_stream < 2 || (words_per_stream & 1) ||
         n_doubles < 0 || (int64_t)n_streams * words_per_stream < 2 * n_doubles)
-        return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_fill: bad argument (streams %d, pos %d, stride %lld, n %lld)",
+        return n2v::fail(N2V_ERR_INVALID, "%s: bad argument (streams %d, pos %d, stride %lld, n %lld)", what,
                          (int)n_streams, (int)pos, (long long)words_per_stream, (long long)n_doubles);
     if (n_doubles == 0) return N2V_OK;
-    if (!out) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_fill: null output");
-    hipLaunchKernelGGL(mt_fill_kernel, dim3((unsigned)n_streams), dim3(64), 0, (hipStream_t)stream, states, (int)pos,
-                       words_per_stream, 2 * n_doubles, out, final_state);
-    return n2v::check_launch("n2v_mt19937_fill");
+    if (!out) return n2v::fail(N2V_ERR_INVALID, "%s: null output", what);
+    if (pairs_per_walk == 0) {
+        hipLaunchKernelGGL(mt_fill_kernel<0>, dim3((unsigned)n_streams), dim3(64), kFillLdsHead, (hipStream_t)stream, states,
+                           (int)pos, words_per_stream, 2 * n_doubles, out, final_state, TileMap{0u, 0u, 0u}, 0);
+        return n2v::check_launch(what);
+    }
+    // the in-stream split works on 32-bit offsets: a stream's doubles plus one segment must stay below 2^32
+    if (pairs_per_walk < 1 || pairs_per_walk > (1 << 24) || words_per_stream / 2 + 2 * (int64_t)pairs_per_walk + 2 >= (1LL << 32))
+        return n2v::fail(N2V_ERR_INVALID, "%s: pairs_per_walk %d / stride %lld out of range", what, (int)pairs_per_walk,
+                         (long long)words_per_stream);
+    if (((uintptr_t)out & 63) != 0) return n2v::fail(N2V_ERR_INVALID, "%s: output not 64-byte aligned", what);
+    const uint32_t dpw = 2u * (uint32_t)pairs_per_walk;
+    const TileMap tm{dpw, (uint32_t)pairs_per_walk, (uint32_t)((1ULL << 32) / dpw)};
+    // ring: one group of four segments (4 * dpw doubles) plus one block of fresh doubles (312) and the straddling one
+    int ring_log2 = 0;
+    while ((1LL << ring_log2) < 4LL * dpw + 320) ++ring_log2;
+    const char* env = getenv("N2V_MT_TILED_DIRECT");      // A/B switch for tools/mt_probe2.py
+    if (ring_log2 <= 12 && !(env && env[0] == '1')) {     // <= 32 KiB of LDS per wavefront (L <= 473)
+        hipLaunchKernelGGL(mt_fill_kernel<2>, dim3((unsigned)n_streams), dim3(64), kFillLdsHead + (sizeof(double) << ring_log2),
+                           (hipStream_t)stream, states, (int)pos, words_per_stream, 2 * n_doubles, out, final_state, tm,
+                           ring_log2);
+    } else {
+        hipLaunchKernelGGL(mt_fill_kernel<1>, dim3((unsigned)n_streams), dim3(64), kFillLdsHead, (hipStream_t)stream, states,
+                           (int)pos, words_per_stream, 2 * n_doubles, out, final_state, tm, 0);
+    }
+    return n2v::check_launch(what);
+}
+
+extern "C" int n2v_mt19937_fill(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
+                                int64_t n_doubles, double* out, uint32_t* final_state, void* stream) {
+    return fill_common("n2v_mt19937_fill", states, n_streams, pos, words_per_stream, n_doubles, 0, out, final_state, stream);
+}
+
+extern "C" int n2v_mt19937_fill_tiled(const uint32_t* states, int32_t n_streams, int32_t pos, int64_t words_per_stream,
+                                      int64_t n_doubles, int32_t pairs_per_walk, double* out, uint32_t* final_state,
+                                      void* stream) {
+    if (pairs_per_walk < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_mt19937_fill_tiled: pairs_per_walk %d", (int)pairs_per_walk);
+    return fill_common("n2v_mt19937_fill_tiled", states, n_streams, pos, words_per_stream, n_doubles, pairs_per_walk, out,
+                       final_state, stream);
 }

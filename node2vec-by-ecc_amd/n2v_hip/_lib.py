@@ -17,6 +17,7 @@ N2V_OK = 0
 N2V_STATUS_ZERO_NORM = 1
 RNG_UNIFORMS = 0
 RNG_PHILOX = 1
+RNG_UNIFORMS_TILED = 2
 
 # name -> (restype, argtypes); mirrors include/n2v_hip.h, n2v_bine.h and n2v_sim.h one to one
 _i64, _i32, _u64, _f64, _ptr = C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_void_p
@@ -39,8 +40,9 @@ SIGNATURES = {
     "n2v_mt19937_jump_polys_host": (C.c_int, [_i64, _i32, _ptr]),
     "n2v_mt19937_jump_device": (C.c_int, [_ptr, _i32, _ptr, _i32, _ptr]),
     "n2v_mt19937_fill": (C.c_int, [_ptr, _i32, _i32, _i64, _i64, _ptr, _ptr, _ptr]),
+    "n2v_mt19937_fill_tiled": (C.c_int, [_ptr, _i32, _i32, _i64, _i64, _i32, _ptr, _ptr, _ptr]),
     "n2v_build_fat_slots": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "n2v_walk_fat": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr, _u64,
+    "n2v_walk_fat": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr, _i64, _u64,
                                _ptr, _ptr, _ptr]),
     "n2v_walk_on_the_fly": (C.c_int, [_ptr, _ptr, _ptr, _f64, _f64, _i32, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i32,
                                       _i32, _ptr, _ptr, _u64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),

@@ -307,9 +307,11 @@ class WalkEngine:
 
     # ------------------------------------------------------------------ walks
     def walk(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
-             pos_begin=0, pos_count=None, round_begin=0, out=None, layout=None):
+             pos_begin=0, pos_count=None, round_begin=0, out=None, layout=None, uoff_round_stride=0):
         """Launch the walk kernel.  ``starts``: int32 device tensor of dense ids (the
-        start order).  Returns (walks int32[n_local, L], lens int32[n_local]) on device."""
+        start order).  Returns (walks int32[n_local, L], lens int32[n_local]) on device.
+        uoff_round_stride > 0: walk_uoff holds one round's offsets (pos_count entries) and every round consumes
+        that many uniforms (include/n2v_hip.h, n2v_walk_fat); expanded here for the thin-table kernel."""
         if not self.ready:
             raise RuntimeError("preprocess() first")
         d = self.device
@@ -327,8 +329,10 @@ class WalkEngine:
             else:
                 walks, lens = out
                 assert walks.shape == (n_local, L) and walks.dtype == torch.int32 and walks.is_contiguous()
-            mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
+            mode = {"uniforms": _lib.RNG_UNIFORMS, "uniforms_tiled": _lib.RNG_UNIFORMS_TILED}.get(rng, _lib.RNG_PHILOX)
             use_fat = self.edge_fat is not None if layout is None else (layout == "fat")
+            if mode == _lib.RNG_UNIFORMS_TILED and not use_fat:
+                raise ValueError("the tiled uniform layout is read by the fat-table walk kernel only")
             if not use_fat and self.edge_slots is None:
                 raise RuntimeError("thin tables were not built (preprocess(fat=False) or fat='both')")
             if use_fat:
@@ -337,8 +341,11 @@ class WalkEngine:
                 _lib.check(self.lib.n2v_walk_fat(
                     _lib.ptr(self.row_ptr), _lib.ptr(self.node_fat), _lib.ptr(self.edge_fat), _lib.ptr(starts),
                     n_starts, pos_begin, pos_count, round_begin, num_rounds, L, mode, _lib.ptr(uniforms),
-                    _lib.ptr(walk_uoff), int(seed) & (2**64 - 1), _lib.ptr(walks), _lib.ptr(lens), self._stream()))
+                    _lib.ptr(walk_uoff), int(uoff_round_stride) if walk_uoff is not None else 0,
+                    int(seed) & (2**64 - 1), _lib.ptr(walks), _lib.ptr(lens), self._stream()))
             else:
+                if uoff_round_stride and walk_uoff is not None:
+                    walk_uoff = expand_round_offsets(walk_uoff, num_rounds, uoff_round_stride)
                 _lib.check(self.lib.n2v_walk(
                     _lib.ptr(self.row_ptr), _lib.ptr(self.node_slots), _lib.ptr(self.recs),
                     _lib.ptr(self.edge_slots), _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin,
@@ -347,7 +354,7 @@ class WalkEngine:
         return walks, lens
 
     def walk_on_the_fly(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
-                         pos_begin=0, pos_count=None, round_begin=0, out=None):
+                         pos_begin=0, pos_count=None, round_begin=0, out=None, uoff_round_stride=0):
         """Launch the on-the-fly walk kernel (no stored edge tables; src/node2vec.py:97-111).
         Same arguments and results as WalkEngine.walk."""
         d = self.device
@@ -377,6 +384,8 @@ class WalkEngine:
                                                               device=d)
             status = torch.zeros(1, dtype=torch.int32, device=d)
             mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
+            if uoff_round_stride and walk_uoff is not None:
+                walk_uoff = expand_round_offsets(walk_uoff, num_rounds, uoff_round_stride)
             _lib.check(self.lib.n2v_walk_on_the_fly(
                 _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), self.p, self.q,
                 0 if self.csr.directed else 1, self.max_degree,
@@ -387,6 +396,12 @@ class WalkEngine:
             if int(status.item()) & _lib.N2V_STATUS_ZERO_NORM:
                 raise ZeroDivisionError("float division by zero")
         return walks, lens
+
+
+def expand_round_offsets(uoff_round, num_rounds, stride):
+    """One round's offsets + a per-round stride -> the per-walk offset array of the kernels that take no stride."""
+    r = torch.arange(num_rounds, dtype=torch.int64, device=uoff_round.device) * int(stride)
+    return (r[:, None] + uoff_round[None, :]).reshape(-1).contiguous()
 
 
 def alias_setup_device(prob_tables, device=None):

@@ -377,24 +377,36 @@ class Graph():
         walks = torch.empty((cnt * num_walks, L), dtype=torch.int32, device=d)
         lens = torch.empty(cnt * num_walks, dtype=torch.int32, device=d)
         st0 = np.random.get_state()
+        self._walk = eng.walk
+        tiled = self._tiled_uniforms_ok(L)
         for it in range(num_walks):
             if cnt == 0:
                 break
             np.random.set_state(st0)
             _mt.advance_global_state((per_round * it + base))
-            U = self._global_uniforms(max(seg, 2), d)
-            eng.walk(eng.start_order, 1, L, rng="uniforms", uniforms=U, walk_uoff=uoff, pos_begin=b, pos_count=cnt,
-                     round_begin=it, out=(walks[it * cnt:(it + 1) * cnt], lens[it * cnt:(it + 1) * cnt]))
+            U = self._global_uniforms(max(seg, 2), d, L - 1 if tiled else None)
+            eng.walk(eng.start_order, 1, L, rng="uniforms_tiled" if tiled else "uniforms", uniforms=U, walk_uoff=uoff,
+                     pos_begin=b, pos_count=cnt, round_begin=it,
+                     out=(walks[it * cnt:(it + 1) * cnt], lens[it * cnt:(it + 1) * cnt]))
         np.random.set_state(st0)
         _mt.advance_global_state(per_round * num_walks)
         return WalkCorpus(walks, lens, self._csr.labels)
 
-    def _global_uniforms(self, n, device):
+    def _global_uniforms(self, n, device, tiled_pairs=None, out=None):
         """The next n doubles of numpy's global MT19937 stream as a device tensor: generated on
-        the GPU by jump-ahead (default) or by numpy on the host (`host_rng = True`)."""
+        the GPU by jump-ahead (default) or by numpy on the host (`host_rng = True`).  tiled_pairs = L-1: in the
+        fat walk kernel's tiled layout (n2v_hip/mt19937.py)."""
         if getattr(self, "host_rng", False):
+            assert not tiled_pairs and out is None
             return torch.from_numpy(np.random.random_sample(n)).to(device)
-        return _mt.global_uniforms_device(n, device)
+        return _mt.global_uniforms_device(n, device, tiled_pairs=tiled_pairs, out=out)
+
+    def _tiled_uniforms_ok(self, L):
+        """Tiled uniforms need the fat-table kernel, device-side generation and walks that cannot end early (the
+        callers check the last)."""
+        eng = self._engine
+        return bool(L > 1 and not getattr(self, "host_rng", False) and not getattr(self, "linear_uniforms", False)
+                    and getattr(self, "_walk", None) == eng.walk and eng.edge_fat is not None)
 
     def _resolve_stream_offsets(self, starts, n, num_walks, L, active):
         """Directed graph with reachable sinks: a walk that ends early consumes fewer uniforms, so the position
@@ -451,34 +463,41 @@ class Graph():
         eng = self._engine
         d = eng.device
         W = n * num_walks
+        step = 2 * (L - 1)
         active = (eng.deg[starts.long()] > 0)
-        per_round = active.to(torch.int64) * (2 * (L - 1))
-        uoff = torch.cumsum(per_round.repeat(num_walks), 0)
-        total_full = int(uoff[-1].item())
-        uoff = torch.cat([torch.zeros(1, dtype=torch.int64, device=d), uoff[:-1]]).contiguous()
-        if total_full == 0:
-            return self._walk(starts, num_walks, L, rng="uniforms",
-                            uniforms=torch.zeros(2, dtype=torch.float64, device=d), walk_uoff=uoff)
+        per_round = active.to(torch.int64) * step
+        per = int(per_round.sum().item())                   # uniforms one round consumes when no walk ends early
+        if per == 0:
+            return self._walk(starts, num_walks, L, rng="uniforms", uniforms=torch.zeros(2, dtype=torch.float64, device=d),
+                              walk_uoff=torch.zeros(W, dtype=torch.int64, device=d))
         # a walk can end early only at a node without out-neighbours that is reachable,
         # i.e. never on an undirected graph (every visited node has the edge it came by)
         may_end_early = bool(self._csr.directed) and bool((eng.deg == 0).any().item())
         if not may_end_early:
-            # every round consumes the same number of uniforms: stream them round-wise — at most ~4 GiB of the
-            # MT19937 stream in HBM at a time (1 GiB when numpy generates it on the host)
-            per = int(per_round.sum().item())
-            uoff_round = uoff[:n].contiguous()
+            # every round consumes the same number of uniforms (start nodes without edges own none), so a walk's
+            # offset is its offset inside the round + round * per: no per-walk array, nothing of size W is computed
+            # here.  With fat tables the generator writes the uniforms in the walk kernel's tiled layout (64 walks'
+            # segments regrouped step-major: one coalesced 1-KiB read per wavefront and step instead of 64 requests
+            # 2(L-1) doubles apart).  The whole call is generated at once when it fits a quarter of the free memory
+            # (one device-side jump-ahead per chunk is the fixed cost; generation and walk do not overlap on the
+            # chip — a walk launch leaves no wave slots for a second stream — so more chunks only cost more jumps).
+            uoff_round = None if per == n * step else (torch.cumsum(per_round, 0) - per_round).contiguous()
             walks = torch.empty((W, L), dtype=torch.int32, device=d)
             lens = torch.empty(W, dtype=torch.int32, device=d)
-            budget = (1 << 27) if getattr(self, "host_rng", False) else (1 << 29)   # doubles
-            rounds_per_chunk = max(1, min(num_walks, budget // max(per, 1)))
-            it = 0
-            while it < num_walks:
+            host = getattr(self, "host_rng", False)
+            tiled = self._tiled_uniforms_ok(L)
+            rounds_per_chunk = getattr(self, "uniform_chunk_rounds", None)
+            if rounds_per_chunk is None:
+                free = torch.cuda.mem_get_info(d)[0]
+                budget = (1 << 27) if host else max(1 << 27, min(1 << 32, free // 32))   # doubles per chunk (<= 32 GiB)
+                rounds_per_chunk = budget // max(per, 1)
+            rounds_per_chunk = int(max(1, min(num_walks, rounds_per_chunk)))
+            for it in range(0, num_walks, rounds_per_chunk):
                 k = min(rounds_per_chunk, num_walks - it)
-                U = self._global_uniforms(per * k, d)
-                off = uoff[:n * k].contiguous() if k > 1 else uoff_round
-                self._walk(starts, k, L, rng="uniforms", uniforms=U, walk_uoff=off, round_begin=it,
-                         out=(walks[it * n:(it + k) * n], lens[it * n:(it + k) * n]))
-                it += k
+                U = self._global_uniforms(per * k, d, L - 1 if tiled else None)
+                self._walk(starts, k, L, rng="uniforms_tiled" if tiled else "uniforms", uniforms=U, walk_uoff=uoff_round,
+                           uoff_round_stride=per, round_begin=it, out=(walks[it * n:(it + k) * n], lens[it * n:(it + k) * n]))
+                del U
             return walks, lens
         state = np.random.get_state()
         walks, lens = self._resolve_stream_offsets(starts, n, num_walks, L, active)

@@ -403,6 +403,66 @@ def test_degenerate_graphs(n2v):
     assert g.simulate_walks(0, 6) == [] and len(g.simulate_walks(0, 6)) == 0
 
 
+def test_tiled_uniform_layout_is_the_same_stream(n2v):
+    """n2v_mt19937_fill_tiled writes exactly the doubles of n2v_mt19937_fill, at the positions the header documents
+    (segments of 2(L-1) doubles regrouped 64 at a time, step-major) — for partial groups, segments that straddle
+    streams and blocks, odd start positions — and leaves the same global state."""
+    import torch
+    from n2v_hip import mt19937
+    for seed, pre_words, n, pairs in [(3, 0, 158 * 64, 79), (3, 7, 158 * 1000, 79), (4, 301, 2 * 77, 1), (5, 623, 48 * 12345, 24),
+                                      (6, 0, 158 * 200003, 79), (8, 11, 6 * 700001, 3), (9, 2, 158 * 5 + 20, 79)]:
+        np.random.seed(seed)
+        if pre_words:
+            np.random.randint(0, 2**32, size=pre_words, dtype=np.uint32)
+        st0 = np.random.get_state()
+        lin = mt19937.global_uniforms_device(n, "cuda:0")
+        st_lin = np.random.get_state()
+        np.random.set_state(st0)
+        til = mt19937.global_uniforms_device(n, "cuda:0", tiled_pairs=pairs)
+        st_til = np.random.get_state()
+        assert til.numel() == mt19937.tiled_size(n, pairs)
+        idx = torch.from_numpy(mt19937.tiled_index(np.arange(n), pairs)).cuda()
+        assert int(idx.max()) < til.numel() and torch.unique(idx).numel() == n
+        assert torch.equal(til[idx].view(torch.int64), lin.view(torch.int64)), (seed, pre_words, n, pairs)
+        assert st_til[2] == st_lin[2] and np.array_equal(st_til[1], st_lin[1])
+
+
+def test_tiled_and_linear_uniforms_walk_the_same(n2v):
+    """Reference-exact walks read their uniforms from the tiled layout by default (fat tables, no reachable sinks);
+    the linear layout and any chunking of the rounds give the same walks and the same
+    global state — also with start nodes that have no edges (they own no uniforms) and for walk lengths that take
+    the 16-B and the scalar output paths."""
+    import torch
+    rs = np.random.RandomState(5)
+    n, m = 3000, 9000
+    src, dst = rs.randint(0, n - 40, m), rs.randint(0, n - 40, m)     # the last 40 ids stay isolated
+    keep = src != dst
+    import networkx as nx
+    G = nx.Graph()
+    G.add_nodes_from(rs.permutation(n).tolist())
+    G.add_edges_from(zip(src[keep].tolist(), dst[keep].tolist()), weight=1)
+    g = n2v.Graph(G, False, 0.5, 2.0)
+    g.preprocess_transition_probs()
+    assert g._engine.edge_fat is not None
+    for L, r in ((80, 7), (36, 3), (7, 2), (2, 3)):
+        res = []
+        for kw in (dict(linear_uniforms=True), dict(), dict(uniform_chunk_rounds=2), dict(uniform_chunk_rounds=1),
+                   dict(uniform_chunk_rounds=3, linear_uniforms=True)):
+            for k in ("linear_uniforms", "uniform_chunk_rounds"):
+                g.__dict__.pop(k, None)
+            g.__dict__.update(kw)
+            np.random.seed(77)
+            c = g.simulate_walks(r, L)
+            st = np.random.get_state()
+            res.append((c.walks.clone(), c.lens.clone(), st[1].copy(), st[2]))
+        for k in ("linear_uniforms", "uniform_chunk_rounds"):
+            g.__dict__.pop(k, None)
+        for other in res[1:]:
+            assert torch.equal(other[0], res[0][0]) and torch.equal(other[1], res[0][1]), L
+            assert np.array_equal(other[2], res[0][2]) and other[3] == res[0][3]
+        assert int((res[0][1] == 1).sum()) >= 40 * r      # isolated starts: [node]
+
+
 def test_shards_reproduce_the_single_process_walks(n2v):
     """Graph.simulate_walks_shard for every rank of a 3-GPU layout, run one after another on this
     GPU: the union equals simulate_walks row for row — in the reference-exact numpy mode (each
