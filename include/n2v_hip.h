@@ -252,6 +252,9 @@ int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bi
  * centre word and share them among its context pairs; target rows stay in registers for the
  * whole window (negative <= 7). */
 #define N2V_SGNS_SHARE_NEGATIVES 4
+/* OR-ed into update_mode: lift the refusal of combinations that were never scored against the comparator
+ * (walk_splits > 1 with N2V_SGNS_PLAIN / N2V_SGNS_AGENT: the wavefronts of ONE sentence hit the same rows at once). */
+#define N2V_SGNS_UNCHECKED 8
 int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
                    float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
                    int32_t window, int32_t negative, const uint32_t* sample_int,

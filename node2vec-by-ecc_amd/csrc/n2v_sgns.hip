@@ -712,11 +712,16 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
                          (int)row_stride);
     if (lut_bits < 1 || lut_bits > 24) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: lut_bits %d", (int)lut_bits);
     const bool share = (update_mode & N2V_SGNS_SHARE_NEGATIVES) != 0;
-    update_mode &= ~N2V_SGNS_SHARE_NEGATIVES;
+    const bool unchecked = (update_mode & N2V_SGNS_UNCHECKED) != 0;
+    update_mode &= ~(N2V_SGNS_SHARE_NEGATIVES | N2V_SGNS_UNCHECKED);
     if (update_mode < kPlain || update_mode > kAtomic)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: update_mode %d", (int)update_mode);
     if (share && negative > 7) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: shared negatives need negative <= 7");
     if (share && walk_splits != 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: shared negatives need walk_splits == 1");
+    // the centres of ONE sentence dealt to several wavefronts update the same context rows at the same instant: with
+    // non-atomic read-modify-write rows that is where updates are lost most — never scored against the comparator
+    if (walk_splits > 1 && update_mode != kAtomic && !unchecked)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_splits > 1 needs N2V_SGNS_ATOMIC (or N2V_SGNS_UNCHECKED)");
     if (sentences_total < 1 || alpha_batch < 1 || sentences_step < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: bad schedule");
     hipStream_t st = (hipStream_t)stream;
     if (int rc = upload_exp_table()) return rc;

@@ -201,20 +201,3 @@ def test_auto_row_sharing_agrees_with_lossless_mode_at_200k(torch_cuda):
         assert m.update_mode_name == ("agent" if mode == "auto" else "atomic")
     print("AUC auto(agent) %.5f atomic %.5f" % (aucs["auto"], aucs["atomic"]))
     assert aucs["atomic"] > 0.85 and abs(aucs["auto"] - aucs["atomic"]) <= 0.002
-
-
-def test_auto_row_sharing_rule(torch_cuda):
-    """update_mode="auto" (n2v_hip/sgns.py): agent-scope load/store only for vocabularies of >= 131 072 rows trained on
-    >= 600 tokens per row; lossless atomics otherwise — the agent mode equals the atomic one (and the CPU comparator)
-    after 10 walks of 80 per node but trails by 0.005 after 5 walks of 40 and by 0.24 after 2 walks of 40 at 131 072
-    rows (tests/probes/agent_band_probe.py; log under profiles/r02/logs/)."""
-    from n2v_hip import sgns
-    n = sgns.AUTO_AGENT_MIN_WORDS
-    for rows, tokens_per_row, want in ((n, 800, "agent"), (n, 200, "atomic"), (n - 1, 800, "atomic"), (3000, 800, "atomic"),
-                                       (4 * n, 600, "agent"), (4 * n, 599, "atomic")):
-        m = sgns.SgnsModel(rows, dim=64, seed=1)
-        m.build_vocab(counts=np.full(rows, tokens_per_row, dtype=np.int64))
-        assert m.update_mode_name == want, (rows, tokens_per_row, m.update_mode_name)
-    m = sgns.SgnsModel(n, dim=64, seed=1, update_mode="plain")
-    m.build_vocab(counts=np.full(n, 5, dtype=np.int64))
-    assert m.update_mode_name == "plain"

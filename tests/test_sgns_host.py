@@ -398,3 +398,48 @@ def test_merger_without_gpu_has_no_fallback():
     mg = sgns.ReplicaMerger([torch.zeros(3, 2)], plan, sgns._SimGroup(2).comm())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mg.snapshot()
+
+
+def test_out_of_band_modes_are_fenced():
+    """Modes that were MEASURED outside BASELINE.json's +-0.002 AUC band cannot be reached by accident:
+    the `auto` row-sharing rule, explicit lossy row sharing on short corpora / small tables, several wavefronts per
+    sentence with lossy rows, merge="hot" on large vocabularies and shared negatives all need allow_out_of_band=True.
+    Pure host logic: runs without a GPU."""
+    import pytest
+    from n2v_hip import sgns
+    n = sgns.AUTO_AGENT_MIN_WORDS
+    for rows, tpr, want in ((n, 800, "agent"), (n, 200, "atomic"), (n - 1, 800, "atomic"), (3000, 800, "atomic"),
+                            (4 * n, 600, "agent"), (4 * n, 599, "atomic")):
+        assert sgns.resolve_update_mode("auto", rows, rows * tpr) == want, (rows, tpr)
+    for mode in ("agent", "plain"):
+        assert sgns.resolve_update_mode(mode, n, 800 * n) == mode                  # long corpus, large table: in the band
+        for rows, tpr in ((n, 200), (n, 5), (3000, 800)):
+            with pytest.raises(sgns.OutOfBandError):
+                sgns.resolve_update_mode(mode, rows, rows * tpr)
+            assert sgns.resolve_update_mode(mode, rows, rows * tpr, allow_out_of_band=True) == mode
+    assert sgns.resolve_update_mode("atomic", 10, 10) == "atomic"
+    with pytest.raises(ValueError):
+        sgns.resolve_update_mode("fast", n, 800 * n)
+    # walk_splits > 1: the lossless mode, silently under `auto`, by request otherwise
+    A, G, P = sgns.UPDATE_MODES["atomic"], sgns.UPDATE_MODES["agent"], sgns.UPDATE_MODES["plain"]
+    assert sgns.launch_update_mode(G, True, 8) == A and sgns.launch_update_mode(P, True, 2) == A
+    assert sgns.launch_update_mode(G, True, 1) == G and sgns.launch_update_mode(A, False, 80) == A
+    with pytest.raises(sgns.OutOfBandError):
+        sgns.launch_update_mode(G, False, 8)
+    assert sgns.launch_update_mode(G, False, 8, allow_out_of_band=True) == G | 8   # N2V_SGNS_UNCHECKED
+    # merge="hot" above the size it was shown to hold at
+    sgns.check_merge_in_band("tsum", 10**7)
+    sgns.check_merge_in_band("hot", 20000)
+    with pytest.raises(sgns.OutOfBandError):
+        sgns.check_merge_in_band("hot", 131072)
+    sgns.check_merge_in_band("hot", 131072, allow_out_of_band=True)
+    with pytest.raises(ValueError):
+        sgns.check_merge_in_band("avg", 10)
+    # shared negatives: refused before anything touches a device
+    with pytest.raises(sgns.OutOfBandError):
+        sgns.SgnsModel(10, share_negatives=True)
+    with pytest.raises(ValueError):
+        sgns.SgnsModel(10, update_mode="fast")
+    import main as n2v_main
+    assert n2v_main.parse_args(["--input", "x"]).allow_out_of_band is False
+    assert n2v_main.parse_args(["--input", "x", "--allow-out-of-band", "--merge", "hot"]).allow_out_of_band is True
