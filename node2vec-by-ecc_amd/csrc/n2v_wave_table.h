@@ -40,12 +40,37 @@ struct RowCtx {
     int32_t symmetric;    // undirected graph: has_edge(nbr, src) == nbr in row(src), one shared row
 };
 
-// Builds the alias table of the step that arrives at the node whose row starts at `base` (K neighbours) from `src`
-// (src < 0: the first step, i.e. the node table of src/node2vec.py:184-188) in T[0..K): afterwards T[k].q / T[k].J
-// are q[k] / J[k] of alias_setup.  All 64 lanes of the wave call it together.  Returns false when the weights sum
-// to 0 (the reference raises ZeroDivisionError, :150 / :187).
+// Where a table under construction keeps q[k], J[k] and the two index stacks (`aux`): one array of {q, J, aux} slots in
+// LDS or in global memory (AosTable), or q in LDS with J and the stacks in a global scratch (SplitTable: tables too
+// large for LDS slots but whose 8-B q values still fit — q is the randomly accessed part, the stacks are streamed).
 template <typename Slot>
-__device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, int32_t src, int64_t base, int K, int lane) {
+struct AosTable {
+    Slot* T;
+    __device__ __forceinline__ double ldq(int k) const { return T[k].q; }
+    __device__ __forceinline__ void stq(int k, double v) const { T[k].q = v; }
+    __device__ __forceinline__ int ldJ(int k) const { return T[k].J; }
+    __device__ __forceinline__ void stJ(int k, int v) const { T[k].J = v; }
+    __device__ __forceinline__ int ldaux(int pos) const { return T[pos].aux; }
+    __device__ __forceinline__ void staux(int pos, int v) const { T[pos].aux = v; }
+};
+struct SplitTable {
+    double* q;       // LDS
+    int32_t* J;      // global scratch [K]
+    int32_t* aux;    // global scratch [K]
+    __device__ __forceinline__ double ldq(int k) const { return q[k]; }
+    __device__ __forceinline__ void stq(int k, double v) const { q[k] = v; }
+    __device__ __forceinline__ int ldJ(int k) const { return J[k]; }
+    __device__ __forceinline__ void stJ(int k, int v) const { J[k] = v; }
+    __device__ __forceinline__ int ldaux(int pos) const { return aux[pos]; }
+    __device__ __forceinline__ void staux(int pos, int v) const { aux[pos] = v; }
+};
+
+// Builds the alias table of the step that arrives at the node whose row starts at `base` (K neighbours) from `src`
+// (src < 0: the first step, i.e. the node table of src/node2vec.py:184-188): afterwards T.ldq(k) / T.ldJ(k) are q[k] /
+// J[k] of alias_setup.  All 64 lanes of the wave call it together.  Returns false when the weights sum to 0 (the
+// reference raises ZeroDivisionError, :150 / :187).
+template <typename Table>
+__device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table T, int32_t src, int64_t base, int K, int lane) {
     // ---- 1. unnormalised weights in parallel (:142-148); has_edge(nbr, src) is "nbr in row(src)" on an undirected
     //         graph, so all lanes probe ONE row
     for (int k = lane; k < K; k += 64) {
@@ -56,21 +81,21 @@ __device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, int32
         else if (nb == src) u = wt / a.p;
         else if (a.symmetric ? row_contains(a.row_ptr, a.col, src, nb) : row_contains(a.row_ptr, a.col, nb, src)) u = wt;
         else u = wt / a.q;
-        T[k].q = u;
+        T.stq(k, u);
     }
     wave_sync();
     // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149): 64 values per coalesced load, consumed
     //         in order through v_readlane by every lane alike
     double norm = 0.0;
     for (int c = 0; c < K; c += 64) {
-        const double v = (c + lane < K) ? T[c + lane].q : 0.0;
+        const double v = (c + lane < K) ? T.ldq(c + lane) : 0.0;
         const int cnt = min(64, K - c);
         for (int j = 0; j < cnt; ++j) norm = norm + readlane_f64(v, j);
     }
     norm = unid(norm);
     if (norm == 0.0) return false;
     // ---- 3. q = K * (u / norm) (:150 then :253, two roundings) and the two index stacks in index order
-    //         (:252-257): `smaller` grows up from slot 0, `larger` down from slot K-1
+    //         (:252-257): `smaller` grows up from position 0, `larger` down from position K-1
     const double Kd = (double)K;
     int ns = 0, nl = 0;
     for (int c = 0; c < K; c += 64) {
@@ -78,74 +103,92 @@ __device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, int32
         const bool valid = k < K;
         double qk = 0.0;
         if (valid) {
-            qk = Kd * (T[k].q / norm);
-            T[k].q = qk;
-            T[k].J = 0;
+            qk = Kd * (T.ldq(k) / norm);
+            T.stq(k, qk);
+            T.stJ(k, 0);
         }
         const bool is_small = valid && (qk < 1.0);
         const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
         const unsigned long long below = (1ULL << lane) - 1ULL;
-        if (is_small) T[ns + __popcll(ms & below)].aux = k;
-        else if (valid) T[K - (nl + __popcll(ml & below) + 1)].aux = k;
+        if (is_small) T.staux(ns + __popcll(ms & below), k);
+        else if (valid) T.staux(K - (nl + __popcll(ml & below) + 1), k);
         ns += __popcll(ms);
         nl += __popcll(ml);
     }
     ns = uni(ns);
     nl = uni(nl);
     wave_sync();
-    // ---- 4. pairing (:259-268).  Both memory stacks only ever hold entries of the initial classification, popped
-    //         in a fixed order and never modified before they are popped: they are streamed 64 entries at a time,
-    //         one per lane, and handed to the (wave-uniform) loop by v_readlane.
-    int mem_s = ns, mem_l = nl;
-    bool hasS = false, hasL = false;
-    int rsi = 0, rli = 0;
-    double rsq = 0.0, rlq = 0.0;
-    int si = 0, s_cnt = 0, s_pos = 0, li = 0, l_cnt = 0, l_pos = 0;
+    // ---- 4. pairing (:259-268).  The reference pops one index from each stack, sets J[small] = large,
+    //         q[large] = q[large] + q[small] - 1.0 and pushes `large` back on the stack its new q selects.  A pushed
+    //         element is always the next one popped from its stack, so the loop is a two-pointer sweep: the CURRENT
+    //         large absorbs smalls until its q drops below 1; then it is the next small (carried in registers) and
+    //         the next large of the stream absorbs it first.  Both memory stacks only ever hold entries of the
+    //         initial classification, popped in a fixed order and never modified before they are popped: they are
+    //         streamed 64 entries at a time, one per lane.  What is serial is the chain of fp64 adds of one large
+    //         (read through v_readlane, same order and roundings as the reference); J of all smalls a large absorbed
+    //         from one buffer is ONE scatter store.
+    int mem_s = ns, mem_l = nl;            // stack entries not yet loaded into the lane buffers
+    int s_pos = 0, s_cnt = 0, l_pos = 0, l_cnt = 0;
+    int si = 0, li = 0;
     double sq = 0.0, lq = 0.0;
-    while ((mem_s > 0 || hasS) && (mem_l > 0 || hasL)) {
-        int small, large;
-        double qs, ql;
-        if (hasS) {                       // smaller.pop(): the element the previous iteration pushed
-            small = rsi; qs = rsq; hasS = false;
-            if (lane == 0) T[small].q = qs;
-        } else {
-            if (s_pos == s_cnt) {         // next <= 64 entries of `smaller`, in pop order (top = position mem_s-1)
+    bool carried = false;                  // a large whose q dropped below 1: the top of `smaller`
+    int cs_i = 0;
+    double cs_q = 0.0;
+    for (;;) {
+        if (l_pos == l_cnt) {              // next <= 64 entries of `larger` (top = position K - mem_l, then upwards)
+            if (mem_l == 0) break;
+            const int pos = K - mem_l + lane;
+            l_cnt = min(64, mem_l);
+            if (lane < l_cnt) { li = T.ldaux(pos); lq = T.ldq(li); }
+            mem_l -= l_cnt;
+            l_pos = 0;
+        }
+        const int large = __builtin_amdgcn_readlane(li, l_pos);
+        double ql = readlane_f64(lq, l_pos);
+        ++l_pos;
+        if (carried) {                     // smaller.pop() is the element the previous large became
+            if (lane == 0) { T.stq(cs_i, cs_q); T.stJ(cs_i, large); }     // :263
+            carried = false;
+            ql = ql + cs_q;                // :264, left to right
+            ql = ql - 1.0;
+            if (__ballot(ql < 1.0) != 0ULL) { carried = true; cs_i = large; cs_q = ql; continue; }
+        }
+        bool dry = false;
+        for (;;) {
+            if (s_pos == s_cnt) {          // next <= 64 entries of `smaller`, in pop order (top = position mem_s - 1)
+                if (mem_s == 0) { dry = true; break; }
                 const int pos = mem_s - 1 - lane;
-                if (pos >= 0) { si = T[pos].aux; sq = T[si].q; }
                 s_cnt = min(64, mem_s);
+                if (lane < s_cnt) { si = T.ldaux(pos); sq = T.ldq(si); }
+                mem_s -= s_cnt;
                 s_pos = 0;
             }
-            small = __builtin_amdgcn_readlane(si, s_pos);
-            qs = readlane_f64(sq, s_pos);
-            ++s_pos;
-            --mem_s;
-        }
-        if (hasL) {                       // larger.pop()
-            large = rli; ql = rlq; hasL = false;
-        } else {
-            if (l_pos == l_cnt) {         // next <= 64 entries of `larger` (top = position K-mem_l, then upwards)
-                const int pos = K - mem_l + lane;
-                if (pos < K) { li = T[pos].aux; lq = T[li].q; }
-                l_cnt = min(64, mem_l);
-                l_pos = 0;
+            const int first = s_pos;
+            bool demoted = false;
+            for (;;) {                     // two exits, each a scalar compare + branch
+                const double qs = readlane_f64(sq, s_pos);
+                ++s_pos;
+                ql = ql + qs;              // :264
+                ql = ql - 1.0;
+                if (__ballot(ql < 1.0) != 0ULL) { demoted = true; break; }
+                if (s_pos >= s_cnt) break;
             }
-            large = __builtin_amdgcn_readlane(li, l_pos);
-            ql = readlane_f64(lq, l_pos);
-            ++l_pos;
-            --mem_l;
+            if (lane >= first && lane < s_pos) T.stJ(si, large);            // :263 for every small of this run
+            if (demoted) { carried = true; cs_i = large; cs_q = ql; break; }
         }
-        if (lane == 0) T[small].J = large;          // :263
-        double t = ql + qs;                          // :264, left to right
-        t = t - 1.0;
-        if (uni((int)(t < 1.0))) { hasS = true; rsi = large; rsq = t; }
-        else { hasL = true; rli = large; rlq = t; }
+        if (dry) {                         // `smaller` is empty: the large stays on `larger` with its current q
+            if (lane == 0) T.stq(large, ql);
+            break;
+        }
     }
-    if (lane == 0) {
-        if (hasS) T[rsi].q = rsq;
-        if (hasL) T[rli].q = rlq;
-    }
+    if (carried && lane == 0) T.stq(cs_i, cs_q);
     wave_sync();
     return true;
+}
+
+template <typename Slot>
+__device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, int32_t src, int64_t base, int K, int lane) {
+    return wave_build_table_in(a, AosTable<Slot>{T}, src, base, K, lane);
 }
 
 }  // namespace n2v
