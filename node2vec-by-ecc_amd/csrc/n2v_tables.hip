@@ -24,7 +24,7 @@ namespace {
 using n2v::uni;
 using n2v::uni64;
 
-constexpr int kLdsSlots = 512;   // 8 KiB per wave, 32 KiB per 4-wave workgroup -> 5 workgroups per CU
+constexpr int kLdsSlots = 512;   // 8 KiB per wave (+ 0.5 KiB feed + 1.5 KiB source row): 40 KiB per 4-wave workgroup -> 4 workgroups per CU
 
 // in-place view of a fat slot while its table is being built: q, J and aux sit where the final slot keeps
 // q and the first two words of the `keep` record; conversion to the final form rewrites the whole slot
@@ -69,14 +69,39 @@ __device__ __forceinline__ void emit_fat(const TabArgs& a, const Slot* T, int64_
     }
 }
 
+#ifdef N2V_TAB_STAMPS
+// [0..3] phases of wave_build_table (weights, sum, normalise + stacks, pairing), [4] emit, [5] hand-out / table header,
+// for tables in LDS; [8..13] the same for tables built in global memory; [6] / [14] slots
+__device__ unsigned long long g_tab_stamps[16];
+extern "C" int n2v_debug_tab_stamps(unsigned long long* host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tab_stamps), sizeof(g_tab_stamps)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tab_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 template <bool FAT>
 __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
     __shared__ n2v_alias_slot lds[4 * kLdsSlots];
+    __shared__ double feed[4 * n2v::kFeed];
+    __shared__ int32_t rows[4 * n2v::kRowCache];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     n2v_alias_slot* Tl = lds + wv * kLdsSlots;
+    int32_t* my_row = rows + wv * n2v::kRowCache;
+    n2v::WaveScratch ws{feed + wv * n2v::kFeed, my_row, -1};
+    int32_t cached_src = -1;               // consecutive CSR entries share their source: its row is staged once
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     bool zero = false;
+#ifdef N2V_TAB_STAMPS
+    unsigned long long st_l[8] = {0}, st_g[8] = {0};
+    unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
+#define N2V_KSTAMP(arr, i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); arr[i] += now_ - t_last_; t_last_ = now_; } while (0)
+    unsigned long long* stl = st_l; unsigned long long* stg = st_g;
+#else
+#define N2V_KSTAMP(arr, i) do { } while (0)
+    unsigned long long* stl = nullptr; unsigned long long* stg = nullptr;
+#endif
     // Tables are handed out kChunk at a time from a shared counter (table sizes span 10 ... 16 614 slots on C3, so
     // a static assignment leaves the waves with the hubs as the tail); without a counter: static grid-stride.
     int64_t i = a.e_begin + (int64_t)blockIdx.x * 4 + wv, chunk_end = 0;
@@ -98,22 +123,40 @@ __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
         const int K = uni((int)(a.g.row_ptr[dst + 1] - base));
         if (K == 0) continue;
         const int64_t t0 = uni64(a.edge_off[e]);
+        if (src != cached_src) {
+            ws.row_n = n2v::wave_cache_row(a.g, my_row, src, lane);
+            cached_src = src;
+        }
         if (K <= kLdsSlots) {
-            if (!n2v::wave_build_table(a.g, Tl, src, base, K, lane)) { zero = true; continue; }
+            N2V_KSTAMP(st_l, 5);
+            if (!n2v::wave_build_table(a.g, Tl, ws, src, base, K, lane, stl)) { zero = true; continue; }
+#ifdef N2V_TAB_STAMPS
+            t_last_ = __builtin_amdgcn_s_memtime(); st_l[6] += K;
+#endif
             if (FAT) emit_fat(a, Tl, t0, base, K, lane);
             else for (int k = lane; k < K; k += 64) { n2v_alias_slot s = Tl[k]; s.aux = 0; a.thin[t0 + k] = s; }
             __builtin_amdgcn_wave_barrier();   // the LDS slice is reused by the next table
+            N2V_KSTAMP(st_l, 4);
         } else if (FAT) {
+            N2V_KSTAMP(st_g, 5);
             fat_build_slot* Tg = reinterpret_cast<fat_build_slot*>(a.fat + t0);
-            if (!n2v::wave_build_table(a.g, Tg, src, base, K, lane)) { zero = true; continue; }
+            if (!n2v::wave_build_table(a.g, Tg, ws, src, base, K, lane, stg)) { zero = true; continue; }
+#ifdef N2V_TAB_STAMPS
+            t_last_ = __builtin_amdgcn_s_memtime(); st_g[6] += K;
+#endif
             emit_fat(a, Tg, t0, base, K, lane);  // in place: slot k is rewritten from its own q, J only
+            N2V_KSTAMP(st_g, 4);
         } else {
             n2v_alias_slot* Tg = a.thin + t0;
-            if (!n2v::wave_build_table(a.g, Tg, src, base, K, lane)) { zero = true; continue; }
+            if (!n2v::wave_build_table(a.g, Tg, ws, src, base, K, lane)) { zero = true; continue; }
             for (int k = lane; k < K; k += 64) Tg[k].aux = 0;
         }
     }
     if (zero && lane == 0) atomicOr(a.status, N2V_STATUS_ZERO_NORM);
+#ifdef N2V_TAB_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 7; ++i) { atomicAdd(&g_tab_stamps[i], st_l[i]); atomicAdd(&g_tab_stamps[8 + i], st_g[i]); }
+#endif
 }
 
 }  // namespace
@@ -136,7 +179,7 @@ extern "C" int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_pt
     TabArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, src_of, edge_off, order, e_begin, e_end, recs, thin, fat, status,
               reinterpret_cast<unsigned long long*>(work_counter)};
     int64_t blocks = (e_end - e_begin + 3) / 4;
-    if (blocks > 256 * 5 * 8) blocks = 256 * 5 * 8;   // 5 resident workgroups per CU by LDS; tables are handed out in a grid-stride loop
+    if (blocks > 256 * 4 * 8) blocks = 256 * 4 * 8;   // 4 resident workgroups per CU by LDS; tables are handed out in a grid-stride loop
     if (fat) hipLaunchKernelGGL((edge_tables_wave_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((edge_tables_wave_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return n2v::check_launch("n2v_build_edge_tables_wave");

@@ -44,11 +44,15 @@ struct OtfArgs {
 
 __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
     __shared__ n2v_alias_slot lds[4 * kLdsSlots];
+    __shared__ double feed[4 * n2v::kFeed];
+    __shared__ int32_t rows[4 * n2v::kRowCache];
     const int lane = threadIdx.x & 63;
     // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from
     // it (walk id, loop bounds, table sizes) is scalar and loops branch on SCC instead of EXEC
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     n2v_alias_slot* Tl = lds + wv * kLdsSlots;
+    int32_t* my_row = rows + wv * n2v::kRowCache;
+    n2v::WaveScratch ws{feed + wv * n2v::kFeed, my_row, -1};
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
     n2v_alias_slot* Tg = a.scratch + wave_global * a.max_degree;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -70,8 +74,9 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
             const int K = uni((int)(a.g.row_ptr[cur + 1] - base));
             if (K == 0) break;  // dead end (:50-51)
             bool ok;
-            if (K <= kLdsSlots) ok = n2v::wave_build_table(a.g, Tl, prev, base, K, lane);
-            else ok = n2v::wave_build_table(a.g, Tg, prev, base, K, lane);
+            ws.row_n = n2v::wave_cache_row(a.g, my_row, prev, lane);     // has_edge(nbr, prev): prev's row, staged in LDS
+            if (K <= kLdsSlots) ok = n2v::wave_build_table(a.g, Tl, ws, prev, base, K, lane);
+            else ok = n2v::wave_build_table(a.g, Tg, ws, prev, base, K, lane);
             if (!ok) { failed = true; break; }
             double u1, u2;
             const uint32_t t = (uint32_t)(len - 1);
@@ -116,9 +121,9 @@ extern "C" int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, c
         return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: rng_mode %d", (int)rng_mode);
     if (rng_mode == N2V_RNG_UNIFORMS && walk_length > 1 && !uniforms)
         return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: parity mode needs a uniform buffer");
-    // grid: as many resident waves as the scratch rows allow (5 workgroups of 4 waves per CU by LDS)
+    // grid: as many resident waves as the scratch rows allow (4 workgroups of 4 waves per CU by LDS)
     int64_t blocks = (n_local + 3) / 4;
-    if (blocks > 256 * 5) blocks = 256 * 5;
+    if (blocks > 256 * 4) blocks = 256 * 4;   // 40 KiB of LDS per workgroup: 4 per CU
     if (max_degree > kLdsSlots) {
         if (!scratch) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: scratch needed (max degree %lld > %d)",
                                        (long long)max_degree, kLdsSlots);

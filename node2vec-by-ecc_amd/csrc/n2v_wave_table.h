@@ -69,8 +69,55 @@ struct SplitTable {
 // (src < 0: the first step, i.e. the node table of src/node2vec.py:184-188): afterwards T.ldq(k) / T.ldJ(k) are q[k] /
 // J[k] of alias_setup.  All 64 lanes of the wave call it together.  Returns false when the weights sum to 0 (the
 // reference raises ZeroDivisionError, :150 / :187).
+#ifdef N2V_TAB_STAMPS   // diagnostic build only (tools/lab/tab_stamps.sh): shader cycles per phase, summed over waves
+#define N2V_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamps[i] += now_ - t_last_; t_last_ = now_; } while (0)
+#else
+#define N2V_STAMP(i) do { } while (0)
+#endif
+
+// Per-wave LDS work area of wave_build_table_in.
+//   feed: 64 doubles.  The left-to-right sum consumes its operands from here by broadcast reads (every lane reads the
+//         same address: one LDS cycle, one instruction per operand) instead of two v_readlane per double —
+//         profiles/r03: the readlane-fed sum cost 106-124 wave-cycles per slot, the LDS-fed one 41-43.  (The pairing
+//         stays register-fed: an LDS read inside its dependent chain cost more latency than two v_readlane cost issue.)
+//   row : the sorted row of `src` (undirected graphs), so that has_edge(nbr, src) is a binary search in LDS instead of
+//         log2(deg(src)) dependent global loads per slot (297 wave-cycles per slot for tables in LDS);
+//         row_n < 0: not cached (row longer than kRowCache, directed graph, first step) -> search in global memory.
+constexpr int kFeed = 64;
+constexpr int kRowCache = 384;     // with 8 KiB of table slots and the feed: 10 KiB per wave, 4 workgroups per CU
+struct WaveScratch {
+    double* feed;          // LDS [kFeed]
+    const int32_t* row;    // LDS [row_n] or nullptr
+    int row_n;
+};
+
+// fills ws_row[0..S) with row(src) when it fits; returns the row_n to pass on (all lanes call it)
+__device__ __forceinline__ int wave_cache_row(const RowCtx& a, int32_t* ws_row, int32_t src, int lane) {
+    if (src < 0 || !a.symmetric) return -1;
+    const int64_t b = uni64(a.row_ptr[src]);
+    const int S = uni((int)(a.row_ptr[src + 1] - b));
+    if (S > kRowCache) return -1;
+    for (int i = lane; i < S; i += 64) ws_row[i] = a.col[b + i];
+    wave_sync();
+    return S;
+}
+
+__device__ __forceinline__ bool lds_row_contains(const int32_t* row, int n, int32_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < n && row[lo] == v;
+}
+
 template <typename Table>
-__device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table T, int32_t src, int64_t base, int K, int lane) {
+__device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table T, const WaveScratch ws, int32_t src,
+                                                    int64_t base, int K, int lane, unsigned long long* stamps = nullptr) {
+#ifdef N2V_TAB_STAMPS
+    unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
+#endif
     // ---- 1. unnormalised weights in parallel (:142-148); has_edge(nbr, src) is "nbr in row(src)" on an undirected
     //         graph, so all lanes probe ONE row
     for (int k = lane; k < K; k += 64) {
@@ -79,20 +126,30 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
         double u;
         if (src < 0) u = wt;
         else if (nb == src) u = wt / a.p;
-        else if (a.symmetric ? row_contains(a.row_ptr, a.col, src, nb) : row_contains(a.row_ptr, a.col, nb, src)) u = wt;
+        else if (ws.row_n >= 0 ? lds_row_contains(ws.row, ws.row_n, nb)
+                 : a.symmetric ? row_contains(a.row_ptr, a.col, src, nb) : row_contains(a.row_ptr, a.col, nb, src)) u = wt;
         else u = wt / a.q;
         T.stq(k, u);
     }
     wave_sync();
-    // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149): 64 values per coalesced load, consumed
-    //         in order through v_readlane by every lane alike
+    N2V_STAMP(0);
+    // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149): 64 values per coalesced load, parked in
+    //         LDS and added in order by every lane alike (broadcast reads)
     double norm = 0.0;
     for (int c = 0; c < K; c += 64) {
-        const double v = (c + lane < K) ? T.ldq(c + lane) : 0.0;
+        ws.feed[lane] = (c + lane < K) ? T.ldq(c + lane) : 0.0;
+        wave_sync();
         const int cnt = min(64, K - c);
-        for (int j = 0; j < cnt; ++j) norm = norm + readlane_f64(v, j);
+        int j = 0;
+        for (; j + 8 <= cnt; j += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) norm = norm + ws.feed[j + i];
+        }
+        for (; j < cnt; ++j) norm = norm + ws.feed[j];
+        wave_sync();
     }
     norm = unid(norm);
+    N2V_STAMP(1);
     if (norm == 0.0) return false;
     // ---- 3. q = K * (u / norm) (:150 then :253, two roundings) and the two index stacks in index order
     //         (:252-257): `smaller` grows up from position 0, `larger` down from position K-1
@@ -118,15 +175,16 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
     ns = uni(ns);
     nl = uni(nl);
     wave_sync();
+    N2V_STAMP(2);
     // ---- 4. pairing (:259-268).  The reference pops one index from each stack, sets J[small] = large,
     //         q[large] = q[large] + q[small] - 1.0 and pushes `large` back on the stack its new q selects.  A pushed
     //         element is always the next one popped from its stack, so the loop is a two-pointer sweep: the CURRENT
     //         large absorbs smalls until its q drops below 1; then it is the next small (carried in registers) and
     //         the next large of the stream absorbs it first.  Both memory stacks only ever hold entries of the
     //         initial classification, popped in a fixed order and never modified before they are popped: they are
-    //         streamed 64 entries at a time, one per lane.  What is serial is the chain of fp64 adds of one large
-    //         (read through v_readlane, same order and roundings as the reference); J of all smalls a large absorbed
-    //         from one buffer is ONE scatter store.
+    //         streamed 64 entries at a time — indices stay in the lanes, the q values are parked in LDS.  What is
+    //         serial is the chain of fp64 adds of one large (same order and roundings as the reference), one broadcast
+    //         LDS read per small; J of all smalls a large absorbed from one buffer is ONE scatter store.
     int mem_s = ns, mem_l = nl;            // stack entries not yet loaded into the lane buffers
     int s_pos = 0, s_cnt = 0, l_pos = 0, l_cnt = 0;
     int si = 0, li = 0;
@@ -144,14 +202,14 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
             l_pos = 0;
         }
         const int large = __builtin_amdgcn_readlane(li, l_pos);
-        double ql = readlane_f64(lq, l_pos);
+        double ql = readlane_f64(lq, l_pos);       // every value of the chain is wave-uniform (v_readlane results)
         ++l_pos;
         if (carried) {                     // smaller.pop() is the element the previous large became
             if (lane == 0) { T.stq(cs_i, cs_q); T.stJ(cs_i, large); }     // :263
             carried = false;
             ql = ql + cs_q;                // :264, left to right
             ql = ql - 1.0;
-            if (__ballot(ql < 1.0) != 0ULL) { carried = true; cs_i = large; cs_q = ql; continue; }
+            if (ql < 1.0) { carried = true; cs_i = large; cs_q = ql; continue; }
         }
         bool dry = false;
         for (;;) {
@@ -165,12 +223,12 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
             }
             const int first = s_pos;
             bool demoted = false;
-            for (;;) {                     // two exits, each a scalar compare + branch
+            for (;;) {
                 const double qs = readlane_f64(sq, s_pos);
                 ++s_pos;
                 ql = ql + qs;              // :264
                 ql = ql - 1.0;
-                if (__ballot(ql < 1.0) != 0ULL) { demoted = true; break; }
+                if (ql < 1.0) { demoted = true; break; }
                 if (s_pos >= s_cnt) break;
             }
             if (lane >= first && lane < s_pos) T.stJ(si, large);            // :263 for every small of this run
@@ -183,12 +241,14 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
     }
     if (carried && lane == 0) T.stq(cs_i, cs_q);
     wave_sync();
+    N2V_STAMP(3);
     return true;
 }
 
 template <typename Slot>
-__device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, int32_t src, int64_t base, int K, int lane) {
-    return wave_build_table_in(a, AosTable<Slot>{T}, src, base, K, lane);
+__device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, const WaveScratch ws, int32_t src, int64_t base,
+                                                 int K, int lane, unsigned long long* stamps = nullptr) {
+    return wave_build_table_in(a, AosTable<Slot>{T}, ws, src, base, K, lane, stamps);
 }
 
 }  // namespace n2v
