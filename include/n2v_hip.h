@@ -87,19 +87,23 @@ int n2v_build_edge_tables(int64_t n_nodes, const int64_t* row_ptr, const int32_t
                           int32_t symmetric, const int64_t* edge_off, const int32_t* order, int64_t e_begin,
                           int64_t e_end, n2v_alias_slot* slots, int32_t* status, void* stream);
 
-/* The same tables (same bits) built by ONE WAVEFRONT per table, with coalesced row reads, tables of up to 512
- * slots staged in LDS and larger ones built in place in the output, written once in the layout the walk reads:
- * exactly one of `thin` (16-B slots at thin[edge_off[e] ...]) and `fat` (32-B n2v_fat_slot at
- * fat[edge_off[e] ...], needs the walk records `recs` of n2v_build_edge_recs, whose table indices address `fat`)
- * is non-NULL.  With `fat` no thin copy of the edge tables has to exist.  work_counter: uint64[1] set to 0 by the
- * caller — tables are then handed to the wavefronts dynamically (sizes differ by three orders of magnitude on a
- * power-law graph), and `order` is not needed; NULL: static assignment.  src/node2vec.py:133-152,240-269.      */
+/* The same tables (same bits) built by ONE WAVEFRONT per table, with coalesced row reads; tables of up to 512 slots
+ * are staged in LDS, of larger ones only the two Vose stacks are kept (in `scratch`) and finished slots go straight to the
+ * output; every output slot is written once, in the layout the walk reads: exactly one of `thin` (16-B slots at
+ * thin[edge_off[e] ...]) and `fat` (32-B n2v_fat_slot at fat[edge_off[e] ...], needs the walk records `recs` of
+ * n2v_build_edge_recs, whose table indices address `fat`) is non-NULL.  With `fat` no thin copy of the edge tables has
+ * to exist.  work_counter: uint64[1] set to 0 by the caller — tables are then handed to the wavefronts dynamically
+ * (sizes differ by three orders of magnitude on a power-law graph), and `order` is not needed; NULL: static assignment.
+ * max_degree: largest out-degree of the graph; scratch: n2v_edge_tables_wave_scratch_bytes(max_degree) bytes, 64-B
+ * aligned (0 bytes / NULL when max_degree <= 512).  src/node2vec.py:133-152,240-269.                              */
 struct n2v_fat_slot;
+int64_t n2v_edge_tables_wave_scratch_bytes(int64_t max_degree);
 int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_ptr, const int32_t* col, const double* w,
                                const int32_t* src_of, double p, double q, int32_t symmetric,
                                const int64_t* edge_off, const int32_t* order, int64_t e_begin, int64_t e_end,
                                const n2v_edge_rec* recs, n2v_alias_slot* thin, struct n2v_fat_slot* fat,
-                               int32_t* status, uint64_t* work_counter, void* stream);
+                               int32_t* status, uint64_t* work_counter, int64_t max_degree, void* scratch,
+                               int64_t scratch_bytes, void* stream);
 
 /* Walk records.  edge_off == NULL: first-order shortcut (p == q == 1), every record
  * points at dst's node table, slot = slot_base + row_ptr[dst].  Otherwise

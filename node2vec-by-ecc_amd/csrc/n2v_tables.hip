@@ -8,8 +8,10 @@
 //     left-to-right fp64 sum (:149) and the stack pairing (:259-268) — but are fed from registers: 64 entries
 //     of a stack are loaded by the 64 lanes at once and consumed through v_readlane, and an element pushed back
 //     is always the next one popped from its stack, so it never touches memory (n2v_vose.h has the argument);
-//   * tables of up to 512 slots live in the wave's slice of LDS while they are built, larger ones are built in
-//     place in the output (hubs);
+//   * tables of up to 512 slots live in the wave's slice of LDS while they are built; of larger ones (hubs) only the
+//     two stacks are stored, in a per-wave scratch, and finished slots are written straight to the output, 64 at a
+//     time (n2v_wave_table.h, wave_build_stream) — building them in place in the output cost 2.65x the output in
+//     write traffic (profiles/r02);
 //   * the result is written once, coalesced, in the layout the walk reads: 16-B thin slots {q, J} or directly
 //     the 32-B "fat" slots {q, record of neighbour k, record of neighbour J[k]} — no thin copy has to exist
 //     next to the fat tables any more.
@@ -24,17 +26,10 @@ namespace {
 using n2v::uni;
 using n2v::uni64;
 
-constexpr int kLdsSlots = 512;   // 8 KiB per wave (+ 0.5 KiB feed + 1.5 KiB source row): 40 KiB per 4-wave workgroup -> 4 workgroups per CU
-
-// in-place view of a fat slot while its table is being built: q, J and aux sit where the final slot keeps
-// q and the first two words of the `keep` record; conversion to the final form rewrites the whole slot
-struct fat_build_slot {
-    double q;
-    int32_t J;
-    int32_t aux;
-    uint32_t pad[4];
-};
-static_assert(sizeof(fat_build_slot) == sizeof(n2v_fat_slot), "fat slot is 32 bytes");
+#ifndef N2V_LDS_SLOTS
+#define N2V_LDS_SLOTS 512
+#endif
+constexpr int kLdsSlots = N2V_LDS_SLOTS;   // 8 KiB per wave (+ 0.5 KiB feed + 1.5 KiB source row): 40 KiB per 4-wave workgroup -> 4 workgroups per CU
 
 struct TabArgs {
     n2v::RowCtx g;
@@ -47,6 +42,8 @@ struct TabArgs {
     n2v_fat_slot* fat;
     int32_t* status;
     unsigned long long* work;    // dynamic hand-out of tables (NULL: static grid-stride)
+    unsigned char* scratch;      // per-wave stacks of the large tables: [n_waves][max_k] x (int32 + double)
+    int64_t max_k;               // scratch entries per wave
 };
 
 constexpr int kChunk = 16;       // tables a wave takes per visit to the shared counter
@@ -80,6 +77,33 @@ extern "C" int n2v_debug_tab_stamps(unsigned long long* host_out, int reset) {
 }
 #endif
 
+// one finished slot -> its output slot (the large tables' emitters; tables in LDS are written by emit_fat / the loop)
+struct FatEmit {
+    const n2v_edge_rec* recs;
+    n2v_fat_slot* fat;       // + t0
+    __device__ __forceinline__ void operator()(bool active, int idx, double q, int J) const {
+        if (!active) return;
+        const uint4 ra = *reinterpret_cast<const uint4*>(recs + idx);   // recs + base
+        const uint4 rb = *reinterpret_cast<const uint4*>(recs + J);
+        uint4 lo, hi;
+        lo.x = (uint32_t)__double2loint(q); lo.y = (uint32_t)__double2hiint(q);
+        lo.z = ra.x; lo.w = ra.w;
+        hi.x = ra.z; hi.y = rb.x; hi.z = rb.w; hi.w = rb.z;
+        uint4* o = reinterpret_cast<uint4*>(fat + idx);
+        o[0] = lo;
+        o[1] = hi;
+    }
+};
+struct ThinEmit {
+    n2v_alias_slot* thin;    // + t0
+    __device__ __forceinline__ void operator()(bool active, int idx, double q, int J) const {
+        if (!active) return;
+        n2v_alias_slot s;
+        s.q = q; s.J = J; s.aux = 0;
+        thin[idx] = s;
+    }
+};
+
 template <bool FAT>
 __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
     __shared__ n2v_alias_slot lds[4 * kLdsSlots];
@@ -102,27 +126,40 @@ __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
 #define N2V_KSTAMP(arr, i) do { } while (0)
     unsigned long long* stl = nullptr; unsigned long long* stg = nullptr;
 #endif
-    // Tables are handed out kChunk at a time from a shared counter (table sizes span 10 ... 16 614 slots on C3, so
-    // a static assignment leaves the waves with the hubs as the tail); without a counter: static grid-stride.
-    int64_t i = a.e_begin + (int64_t)blockIdx.x * 4 + wv, chunk_end = 0;
+    // Tables are taken kChunk at a time: from a shared counter (table sizes span 10 ... 16 614 slots on C3, so a static
+    // assignment leaves the waves with the hubs as the tail) or, without a counter, by static striding.  The next
+    // chunk's counter value is requested before this chunk is worked on, and the headers of a chunk's tables (source,
+    // destination, its row, the table's place: two levels of dependent loads) are fetched by 16 lanes at once —
+    // per table they cost a quarter of a small table's time (profiles/r03/logs/tab_stamps_*.log).
+    unsigned long long nxt = 0, stat = ((unsigned long long)blockIdx.x * 4 + wv) * kChunk;
+    auto request_chunk = [&]() {
+        if (a.work) { if (lane == 0) nxt = atomicAdd(a.work, (unsigned long long)kChunk); }
+        else { nxt = stat; stat += (unsigned long long)n_waves * kChunk; }
+    };
+    request_chunk();
     for (;;) {
-        if (a.work) {
-            if (i >= chunk_end) {
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(a.work, (unsigned long long)kChunk);
-                i = a.e_begin + uni64((int64_t)b);
-                chunk_end = i + kChunk;
-            }
+        const int64_t i0 = a.e_begin + uni64((int64_t)nxt);
+        if (i0 >= a.e_end) break;
+        request_chunk();
+        const int n_in = (int)min((int64_t)kChunk, a.e_end - i0);
+        int32_t h_src = 0, h_dst = 0, h_K = 0;
+        int64_t h_base = 0, h_t0 = 0;
+        if (lane < n_in) {
+            const int64_t e = a.order ? (int64_t)(uint32_t)a.order[i0 + lane] : i0 + lane;
+            h_src = a.src_of[e];
+            h_dst = a.g.col[e];
+            h_base = a.g.row_ptr[h_dst];
+            h_K = (int32_t)(a.g.row_ptr[h_dst + 1] - h_base);
+            h_t0 = a.edge_off[e];
         }
-        if (i >= a.e_end) break;
-        const int64_t i_cur = i;
-        i += a.work ? 1 : n_waves;
-        const int64_t e = a.order ? (int64_t)(uint32_t)uni(a.order[i_cur]) : i_cur;
-        const int32_t src = uni(a.src_of[e]), dst = uni(a.g.col[e]);
-        const int64_t base = uni64(a.g.row_ptr[dst]);
-        const int K = uni((int)(a.g.row_ptr[dst + 1] - base));
+      for (int j = 0; j < n_in; ++j) {
+        const int32_t src = __builtin_amdgcn_readlane(h_src, j);
+        const int K = __builtin_amdgcn_readlane(h_K, j);
         if (K == 0) continue;
-        const int64_t t0 = uni64(a.edge_off[e]);
+        const int64_t base = ((int64_t)__builtin_amdgcn_readlane((int)(h_base >> 32), j) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)h_base, j);
+        const int64_t t0 = ((int64_t)__builtin_amdgcn_readlane((int)(h_t0 >> 32), j) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)h_t0, j);
         if (src != cached_src) {
             ws.row_n = n2v::wave_cache_row(a.g, my_row, src, lane);
             cached_src = src;
@@ -137,20 +174,27 @@ __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
             else for (int k = lane; k < K; k += 64) { n2v_alias_slot s = Tl[k]; s.aux = 0; a.thin[t0 + k] = s; }
             __builtin_amdgcn_wave_barrier();   // the LDS slice is reused by the next table
             N2V_KSTAMP(st_l, 4);
-        } else if (FAT) {
-            N2V_KSTAMP(st_g, 5);
-            fat_build_slot* Tg = reinterpret_cast<fat_build_slot*>(a.fat + t0);
-            if (!n2v::wave_build_table(a.g, Tg, ws, src, base, K, lane, stg)) { zero = true; continue; }
-#ifdef N2V_TAB_STAMPS
-            t_last_ = __builtin_amdgcn_s_memtime(); st_g[6] += K;
-#endif
-            emit_fat(a, Tg, t0, base, K, lane);  // in place: slot k is rewritten from its own q, J only
-            N2V_KSTAMP(st_g, 4);
         } else {
-            n2v_alias_slot* Tg = a.thin + t0;
-            if (!n2v::wave_build_table(a.g, Tg, ws, src, base, K, lane)) { zero = true; continue; }
-            for (int k = lane; k < K; k += 64) Tg[k].aux = 0;
+            N2V_KSTAMP(st_g, 5);
+            // stacks in this wave's scratch row; the output queue overlays the (unused) LDS table slice
+            unsigned char* row = a.scratch + ((int64_t)blockIdx.x * 4 + wv) * a.max_k * 12;
+            const n2v::StreamStacks S{reinterpret_cast<int32_t*>(row + a.max_k * 8), reinterpret_cast<double*>(row)};
+            int32_t* qi = reinterpret_cast<int32_t*>(Tl);
+            bool ok;
+            if (FAT) {
+                n2v::QueueSink<FatEmit> sink{qi, qi + 128, reinterpret_cast<double*>(qi + 256), FatEmit{a.recs + base, a.fat + t0}, lane};
+                ok = n2v::wave_build_stream(a.g, S, ws, sink, src, base, K, lane, stg);
+            } else {
+                n2v::QueueSink<ThinEmit> sink{qi, qi + 128, reinterpret_cast<double*>(qi + 256), ThinEmit{a.thin + t0}, lane};
+                ok = n2v::wave_build_stream(a.g, S, ws, sink, src, base, K, lane, stg);
+            }
+            if (!ok) { zero = true; continue; }
+#ifdef N2V_TAB_STAMPS
+            st_g[6] += K;
+#endif
+            __builtin_amdgcn_wave_barrier();   // the LDS slice is reused by the next table
         }
+      }
     }
     if (zero && lane == 0) atomicOr(a.status, N2V_STATUS_ZERO_NORM);
 #ifdef N2V_TAB_STAMPS
@@ -161,12 +205,25 @@ __global__ void __launch_bounds__(256) edge_tables_wave_kernel(TabArgs a) {
 
 }  // namespace
 
+namespace {
+constexpr int kLdsPerWg = 4 * (kLdsSlots * 16 + n2v::kFeed * 8 + n2v::kRowCache * 4);
+constexpr int kWgPerCu = (160 * 1024 / kLdsPerWg) < 8 ? (160 * 1024 / kLdsPerWg) : 8;
+constexpr int64_t kMaxBlocks = 256 * kWgPerCu;     // every resident workgroup slot of the chip, once: tables are handed out
+static_assert(kLdsSlots * 16 >= 2048, "the output queue of the large tables overlays the LDS table slice");
+inline int64_t scratch_k(int64_t max_degree) { return max_degree <= kLdsSlots ? 0 : (max_degree + 15) / 16 * 16; }
+}  // namespace
+
+extern "C" int64_t n2v_edge_tables_wave_scratch_bytes(int64_t max_degree) {
+    return max_degree < 0 ? -1 : kMaxBlocks * 4 * scratch_k(max_degree) * 12;
+}
+
 extern "C" int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_ptr, const int32_t* col, const double* w,
                                           const int32_t* src_of, double p, double q, int32_t symmetric,
                                           const int64_t* edge_off, const int32_t* order, int64_t e_begin, int64_t e_end,
                                           const n2v_edge_rec* recs, n2v_alias_slot* thin, n2v_fat_slot* fat,
-                                          int32_t* status, uint64_t* work_counter, void* stream) {
-    if (n_nodes < 0 || e_begin < 0 || e_end < e_begin)
+                                          int32_t* status, uint64_t* work_counter, int64_t max_degree, void* scratch,
+                                          int64_t scratch_bytes, void* stream) {
+    if (n_nodes < 0 || e_begin < 0 || e_end < e_begin || max_degree < 0)
         return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: bad range [%lld, %lld)", (long long)e_begin, (long long)e_end);
     if (e_end == e_begin) return N2V_OK;
     if (!row_ptr || !col || !src_of || !edge_off || !status)
@@ -176,10 +233,14 @@ extern "C" int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_pt
     if (fat && !recs) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: fat output needs the edge records");
     if (fat && ((uintptr_t)fat & 31) != 0) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: fat slots not 32-byte aligned");
     if (!(p == p) || !(q == q)) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: p or q is NaN");
+    const int64_t need = n2v_edge_tables_wave_scratch_bytes(max_degree);
+    if (need > 0 && (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 63) != 0))
+        return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_tables_wave: max degree %lld needs %lld bytes of 64-byte aligned scratch "
+                         "(n2v_edge_tables_wave_scratch_bytes), got %lld", (long long)max_degree, (long long)need, (long long)scratch_bytes);
     TabArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, src_of, edge_off, order, e_begin, e_end, recs, thin, fat, status,
-              reinterpret_cast<unsigned long long*>(work_counter)};
-    int64_t blocks = (e_end - e_begin + 3) / 4;
-    if (blocks > 256 * 4 * 8) blocks = 256 * 4 * 8;   // 4 resident workgroups per CU by LDS; tables are handed out in a grid-stride loop
+              reinterpret_cast<unsigned long long*>(work_counter), reinterpret_cast<unsigned char*>(scratch), scratch_k(max_degree)};
+    int64_t blocks = (e_end - e_begin + 4 * kChunk - 1) / (4 * kChunk);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     if (fat) hipLaunchKernelGGL((edge_tables_wave_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((edge_tables_wave_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return n2v::check_launch("n2v_build_edge_tables_wave");

@@ -40,42 +40,13 @@ struct RowCtx {
     int32_t symmetric;    // undirected graph: has_edge(nbr, src) == nbr in row(src), one shared row
 };
 
-// Where a table under construction keeps q[k], J[k] and the two index stacks (`aux`): one array of {q, J, aux} slots in
-// LDS or in global memory (AosTable), or q in LDS with J and the stacks in a global scratch (SplitTable: tables too
-// large for LDS slots but whose 8-B q values still fit — q is the randomly accessed part, the stacks are streamed).
-template <typename Slot>
-struct AosTable {
-    Slot* T;
-    __device__ __forceinline__ double ldq(int k) const { return T[k].q; }
-    __device__ __forceinline__ void stq(int k, double v) const { T[k].q = v; }
-    __device__ __forceinline__ int ldJ(int k) const { return T[k].J; }
-    __device__ __forceinline__ void stJ(int k, int v) const { T[k].J = v; }
-    __device__ __forceinline__ int ldaux(int pos) const { return T[pos].aux; }
-    __device__ __forceinline__ void staux(int pos, int v) const { T[pos].aux = v; }
-};
-struct SplitTable {
-    double* q;       // LDS
-    int32_t* J;      // global scratch [K]
-    int32_t* aux;    // global scratch [K]
-    __device__ __forceinline__ double ldq(int k) const { return q[k]; }
-    __device__ __forceinline__ void stq(int k, double v) const { q[k] = v; }
-    __device__ __forceinline__ int ldJ(int k) const { return J[k]; }
-    __device__ __forceinline__ void stJ(int k, int v) const { J[k] = v; }
-    __device__ __forceinline__ int ldaux(int pos) const { return aux[pos]; }
-    __device__ __forceinline__ void staux(int pos, int v) const { aux[pos] = v; }
-};
-
-// Builds the alias table of the step that arrives at the node whose row starts at `base` (K neighbours) from `src`
-// (src < 0: the first step, i.e. the node table of src/node2vec.py:184-188): afterwards T.ldq(k) / T.ldJ(k) are q[k] /
-// J[k] of alias_setup.  All 64 lanes of the wave call it together.  Returns false when the weights sum to 0 (the
-// reference raises ZeroDivisionError, :150 / :187).
 #ifdef N2V_TAB_STAMPS   // diagnostic build only (tools/lab/tab_stamps.sh): shader cycles per phase, summed over waves
 #define N2V_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamps[i] += now_ - t_last_; t_last_ = now_; } while (0)
 #else
 #define N2V_STAMP(i) do { } while (0)
 #endif
 
-// Per-wave LDS work area of wave_build_table_in.
+// Per-wave LDS work area.
 //   feed: 64 doubles.  The left-to-right sum consumes its operands from here by broadcast reads (every lane reads the
 //         same address: one LDS cycle, one instruction per operand) instead of two v_readlane per double —
 //         profiles/r03: the readlane-fed sum cost 106-124 wave-cycles per slot, the LDS-fed one 41-43.  (The pairing
@@ -112,79 +83,48 @@ __device__ __forceinline__ bool lds_row_contains(const int32_t* row, int n, int3
     return lo < n && row[lo] == v;
 }
 
-template <typename Table>
-__device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table T, const WaveScratch ws, int32_t src,
-                                                    int64_t base, int K, int lane, unsigned long long* stamps = nullptr) {
-#ifdef N2V_TAB_STAMPS
-    unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- 1. unnormalised weights in parallel (:142-148); has_edge(nbr, src) is "nbr in row(src)" on an undirected
-    //         graph, so all lanes probe ONE row
-    for (int k = lane; k < K; k += 64) {
-        const int32_t nb = a.col[base + k];
-        const double wt = a.w ? a.w[base + k] : 1.0;
-        double u;
-        if (src < 0) u = wt;
-        else if (nb == src) u = wt / a.p;
-        else if (ws.row_n >= 0 ? lds_row_contains(ws.row, ws.row_n, nb)
-                 : a.symmetric ? row_contains(a.row_ptr, a.col, src, nb) : row_contains(a.row_ptr, a.col, nb, src)) u = wt;
-        else u = wt / a.q;
-        T.stq(k, u);
-    }
+// unnormalised transition weight of neighbour k of the row at `base` for a step arriving from `src` (:142-148)
+__device__ __forceinline__ double step_weight(const RowCtx& a, const WaveScratch& ws, int32_t src, int64_t base, int k) {
+    const int32_t nb = a.col[base + k];
+    const double wt = a.w ? a.w[base + k] : 1.0;
+    if (src < 0) return wt;
+    if (nb == src) return wt / a.p;
+    const bool adj = ws.row_n >= 0 ? lds_row_contains(ws.row, ws.row_n, nb)
+                     : a.symmetric ? row_contains(a.row_ptr, a.col, src, nb) : row_contains(a.row_ptr, a.col, nb, src);
+    return adj ? wt : wt / a.q;
+}
+
+// norm = norm + v[0] + v[1] + ... strictly left to right (:149): the wave's 64 values are parked in LDS and added in
+// order by every lane alike (broadcast reads); `cnt` of them count
+__device__ __forceinline__ double wave_sum_in_order(const WaveScratch& ws, double norm, double v, int cnt, int lane) {
+    ws.feed[lane] = v;
     wave_sync();
-    N2V_STAMP(0);
-    // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149): 64 values per coalesced load, parked in
-    //         LDS and added in order by every lane alike (broadcast reads)
-    double norm = 0.0;
-    for (int c = 0; c < K; c += 64) {
-        ws.feed[lane] = (c + lane < K) ? T.ldq(c + lane) : 0.0;
-        wave_sync();
-        const int cnt = min(64, K - c);
-        int j = 0;
-        for (; j + 8 <= cnt; j += 8) {
+    int j = 0;
+    for (; j + 8 <= cnt; j += 8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) norm = norm + ws.feed[j + i];
-        }
-        for (; j < cnt; ++j) norm = norm + ws.feed[j];
-        wave_sync();
+        for (int i = 0; i < 8; ++i) norm = norm + ws.feed[j + i];
     }
-    norm = unid(norm);
-    N2V_STAMP(1);
-    if (norm == 0.0) return false;
-    // ---- 3. q = K * (u / norm) (:150 then :253, two roundings) and the two index stacks in index order
-    //         (:252-257): `smaller` grows up from position 0, `larger` down from position K-1
-    const double Kd = (double)K;
-    int ns = 0, nl = 0;
-    for (int c = 0; c < K; c += 64) {
-        const int k = c + lane;
-        const bool valid = k < K;
-        double qk = 0.0;
-        if (valid) {
-            qk = Kd * (T.ldq(k) / norm);
-            T.stq(k, qk);
-            T.stJ(k, 0);
-        }
-        const bool is_small = valid && (qk < 1.0);
-        const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
-        const unsigned long long below = (1ULL << lane) - 1ULL;
-        if (is_small) T.staux(ns + __popcll(ms & below), k);
-        else if (valid) T.staux(K - (nl + __popcll(ml & below) + 1), k);
-        ns += __popcll(ms);
-        nl += __popcll(ml);
-    }
-    ns = uni(ns);
-    nl = uni(nl);
+    for (; j < cnt; ++j) norm = norm + ws.feed[j];
     wave_sync();
-    N2V_STAMP(2);
-    // ---- 4. pairing (:259-268).  The reference pops one index from each stack, sets J[small] = large,
-    //         q[large] = q[large] + q[small] - 1.0 and pushes `large` back on the stack its new q selects.  A pushed
-    //         element is always the next one popped from its stack, so the loop is a two-pointer sweep: the CURRENT
-    //         large absorbs smalls until its q drops below 1; then it is the next small (carried in registers) and
-    //         the next large of the stream absorbs it first.  Both memory stacks only ever hold entries of the
-    //         initial classification, popped in a fixed order and never modified before they are popped: they are
-    //         streamed 64 entries at a time — indices stay in the lanes, the q values are parked in LDS.  What is
-    //         serial is the chain of fp64 adds of one large (same order and roundings as the reference), one broadcast
-    //         LDS read per small; J of all smalls a large absorbed from one buffer is ONE scatter store.
+    return norm;
+}
+
+// ---- Vose's pairing (:259-268) as a two-pointer sweep ----------------------------------------------------------
+// The reference pops one index from each stack, sets J[small] = large, q[large] = q[large] + q[small] - 1.0 and pushes
+// `large` back on the stack its new q selects.  A pushed element is always the next one popped from its stack, so: the
+// CURRENT large absorbs smalls until its q drops below 1; then it is the next small (carried in registers) and the
+// next large of the stream absorbs it first.  Both memory stacks only ever hold entries of the initial classification,
+// popped in a fixed order and never modified before they are popped: they are streamed 64 entries at a time, one per
+// lane.  What is serial is the chain of fp64 adds of one large (read through v_readlane: same order and roundings as
+// the reference); the smalls a large absorbed from one buffer are finalised by ONE call of the sink.
+//   Stacks: load_small(pos, idx&, q&) / load_large(pos, idx&, q&) — entry at stack position pos; `smaller` occupies
+//           positions [0, ns) (top = ns-1), `larger` positions [K-nl, K) (top = K-nl).
+//   Sink:   run(in_run, idx, q, J)  per lane: slot idx is final with (q, J) for the lanes with in_run;
+//           one(idx, q, J)          wave-uniform: one slot is final;
+//           kRest / rest(in, idx, q) slots that were never paired are final with J = 0 and the q they have (only
+//           sinks that emit results need to be told).
+template <typename Stacks, typename Sink>
+__device__ __forceinline__ void wave_pair(const Stacks& S, Sink& out, int K, int ns, int nl, int lane) {
     int mem_s = ns, mem_l = nl;            // stack entries not yet loaded into the lane buffers
     int s_pos = 0, s_cnt = 0, l_pos = 0, l_cnt = 0;
     int si = 0, li = 0;
@@ -197,7 +137,7 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
             if (mem_l == 0) break;
             const int pos = K - mem_l + lane;
             l_cnt = min(64, mem_l);
-            if (lane < l_cnt) { li = T.ldaux(pos); lq = T.ldq(li); }
+            if (lane < l_cnt) S.load_large(pos, li, lq);
             mem_l -= l_cnt;
             l_pos = 0;
         }
@@ -205,7 +145,7 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
         double ql = readlane_f64(lq, l_pos);       // every value of the chain is wave-uniform (v_readlane results)
         ++l_pos;
         if (carried) {                     // smaller.pop() is the element the previous large became
-            if (lane == 0) { T.stq(cs_i, cs_q); T.stJ(cs_i, large); }     // :263
+            out.one(cs_i, cs_q, large);    // :263
             carried = false;
             ql = ql + cs_q;                // :264, left to right
             ql = ql - 1.0;
@@ -217,7 +157,7 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
                 if (mem_s == 0) { dry = true; break; }
                 const int pos = mem_s - 1 - lane;
                 s_cnt = min(64, mem_s);
-                if (lane < s_cnt) { si = T.ldaux(pos); sq = T.ldq(si); }
+                if (lane < s_cnt) S.load_small(pos, si, sq);
                 mem_s -= s_cnt;
                 s_pos = 0;
             }
@@ -231,24 +171,200 @@ __device__ __forceinline__ bool wave_build_table_in(const RowCtx& a, const Table
                 if (ql < 1.0) { demoted = true; break; }
                 if (s_pos >= s_cnt) break;
             }
-            if (lane >= first && lane < s_pos) T.stJ(si, large);            // :263 for every small of this run
+            out.run(lane >= first && lane < s_pos, si, sq, large);         // :263 for every small of this run
             if (demoted) { carried = true; cs_i = large; cs_q = ql; break; }
         }
         if (dry) {                         // `smaller` is empty: the large stays on `larger` with its current q
-            if (lane == 0) T.stq(large, ql);
+            out.one(large, ql, 0);
             break;
         }
     }
-    if (carried && lane == 0) T.stq(cs_i, cs_q);
+    if (carried) out.one(cs_i, cs_q, 0);
+    if (Sink::kRest) {                     // never popped: J stays 0 (:248), q as classified
+        out.rest(lane >= s_pos && lane < s_cnt, si, sq);
+        while (mem_s > 0) {
+            const int pos = mem_s - 1 - lane;
+            const int cnt = min(64, mem_s);
+            if (lane < cnt) S.load_small(pos, si, sq);
+            out.rest(lane < cnt, si, sq);
+            mem_s -= cnt;
+        }
+        out.rest(lane >= l_pos && lane < l_cnt, li, lq);
+        while (mem_l > 0) {
+            const int pos = K - mem_l + lane;
+            const int cnt = min(64, mem_l);
+            if (lane < cnt) S.load_large(pos, li, lq);
+            out.rest(lane < cnt, li, lq);
+            mem_l -= cnt;
+        }
+    }
+}
+
+// ---- table in one array of {q, J, aux} slots (LDS, or global memory for the on-the-fly walk's hub rows) ---------
+template <typename Slot>
+struct AosTable {
+    Slot* T;
+    __device__ __forceinline__ void load_small(int pos, int& idx, double& q) const { idx = T[pos].aux; q = T[idx].q; }
+    __device__ __forceinline__ void load_large(int pos, int& idx, double& q) const { idx = T[pos].aux; q = T[idx].q; }
+};
+template <typename Slot>
+struct AosSink {                           // q of a stream entry is already in place: only J, and q of demoted larges
+    static constexpr bool kRest = false;
+    Slot* T;
+    int lane;
+    __device__ __forceinline__ void run(bool in_run, int idx, double, int J) const { if (in_run) T[idx].J = J; }
+    __device__ __forceinline__ void one(int idx, double q, int J) const { if (lane == 0) { T[idx].q = q; T[idx].J = J; } }
+    __device__ __forceinline__ void rest(bool, int, double) const {}
+};
+
+// Builds the alias table of the step that arrives at the node whose row starts at `base` (K neighbours) from `src`
+// (src < 0: the first step, i.e. the node table of src/node2vec.py:184-188) in T[0..K): afterwards T[k].q / T[k].J
+// are q[k] / J[k] of alias_setup.  All 64 lanes of the wave call it together.  Returns false when the weights sum
+// to 0 (the reference raises ZeroDivisionError, :150 / :187).
+template <typename Slot>
+__device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, const WaveScratch ws, int32_t src, int64_t base,
+                                                 int K, int lane, unsigned long long* stamps = nullptr) {
+#ifdef N2V_TAB_STAMPS
+    unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- 1. unnormalised weights in parallel (:142-148)
+    for (int k = lane; k < K; k += 64) T[k].q = step_weight(a, ws, src, base, k);
+    wave_sync();
+    N2V_STAMP(0);
+    // ---- 2. norm = sum(unnormalized_probs), strictly left to right (:149)
+    double norm = 0.0;
+    for (int c = 0; c < K; c += 64)
+        norm = wave_sum_in_order(ws, norm, (c + lane < K) ? T[c + lane].q : 0.0, min(64, K - c), lane);
+    norm = unid(norm);
+    N2V_STAMP(1);
+    if (norm == 0.0) return false;
+    // ---- 3. q = K * (u / norm) (:150 then :253, two roundings) and the two index stacks in index order
+    //         (:252-257): `smaller` grows up from position 0, `larger` down from position K-1
+    const double Kd = (double)K;
+    int ns = 0, nl = 0;
+    for (int c = 0; c < K; c += 64) {
+        const int k = c + lane;
+        const bool valid = k < K;
+        double qk = 0.0;
+        if (valid) {
+            qk = Kd * (T[k].q / norm);
+            T[k].q = qk;
+            T[k].J = 0;
+        }
+        const bool is_small = valid && (qk < 1.0);
+        const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        if (is_small) T[ns + __popcll(ms & below)].aux = k;
+        else if (valid) T[K - (nl + __popcll(ml & below) + 1)].aux = k;
+        ns += __popcll(ms);
+        nl += __popcll(ml);
+    }
+    ns = uni(ns);
+    nl = uni(nl);
+    wave_sync();
+    N2V_STAMP(2);
+    // ---- 4. pairing (:259-268)
+    AosSink<Slot> sink{T, lane};
+    wave_pair(AosTable<Slot>{T}, sink, K, ns, nl, lane);
     wave_sync();
     N2V_STAMP(3);
     return true;
 }
 
-template <typename Slot>
-__device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, const WaveScratch ws, int32_t src, int64_t base,
-                                                 int K, int lane, unsigned long long* stamps = nullptr) {
-    return wave_build_table_in(a, AosTable<Slot>{T}, ws, src, base, K, lane, stamps);
+// ---- large tables of the table BUILDER: nothing but the two stacks is stored ---------------------------------------
+// A table too large for the wave's LDS slots used to be built in place in its output (q, J and the stack words landed
+// as partial-line writes in the 32-B fat slots before the final slot was written: 2.65x the output in write traffic on
+// C3, profiles/r02).  Here the unnormalised weights are computed twice (once for the sum, once to classify — a column
+// load and a search in the LDS-cached source row) instead of being stored; the classification appends {index, q} to
+// the two stacks, which live in a per-wave scratch and are written and read once, sequentially; the pairing hands every
+// finished slot (index, q, J) to the emitter, which queues 64 of them in LDS and then writes 64 complete output slots.
+struct StreamStacks {                      // per-wave global scratch: idx[K], q[K]
+    int32_t* idx;
+    double* q;
+    __device__ __forceinline__ void load_small(int pos, int& i, double& v) const { i = idx[pos]; v = q[pos]; }
+    __device__ __forceinline__ void load_large(int pos, int& i, double& v) const { i = idx[pos]; v = q[pos]; }
+};
+
+// Emit: void operator()(bool active, int idx, double q, int J) — called by all 64 lanes, writes the output slot of idx.
+template <typename Emit>
+struct QueueSink {
+    static constexpr bool kRest = true;
+    int32_t* qi;                           // LDS [128] slot index
+    int32_t* qJ;                           // LDS [128]
+    double* qq;                            // LDS [128]
+    Emit emit;
+    int lane;
+    int n = 0;                             // queued entries, < 64 between calls
+    __device__ __forceinline__ void flush64() {
+        wave_sync();
+        emit(true, qi[lane], qq[lane], qJ[lane]);
+        wave_sync();
+        const int rem = n - 64;            // < 64: move the tail to the front
+        if (lane < rem) { const int i = qi[64 + lane], J = qJ[64 + lane]; const double q = qq[64 + lane];
+                          qi[lane] = i; qJ[lane] = J; qq[lane] = q; }
+        n = rem;
+    }
+    __device__ __forceinline__ void run(bool in_run, int idx, double q, int J) {
+        const unsigned long long m = __ballot(in_run);
+        if (in_run) { const int p = n + __popcll(m & ((1ULL << lane) - 1ULL)); qi[p] = idx; qJ[p] = J; qq[p] = q; }
+        n += __popcll(m);
+        if (n >= 64) flush64();
+    }
+    __device__ __forceinline__ void one(int idx, double q, int J) {
+        if (lane == 0) { qi[n] = idx; qJ[n] = J; qq[n] = q; }
+        if (++n >= 64) flush64();
+    }
+    __device__ __forceinline__ void rest(bool in, int idx, double q) { run(in, idx, q, 0); }
+    __device__ __forceinline__ void finish() {
+        wave_sync();
+        emit(lane < n, qi[lane], qq[lane], qJ[lane]);
+        n = 0;
+        wave_sync();
+    }
+};
+
+template <typename Emit>
+__device__ __forceinline__ bool wave_build_stream(const RowCtx& a, const StreamStacks S, const WaveScratch ws,
+                                                  QueueSink<Emit>& sink, int32_t src, int64_t base, int K, int lane,
+                                                  unsigned long long* stamps = nullptr) {
+#ifdef N2V_TAB_STAMPS
+    unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- 1 + 2. weights (:142-148) straight into the left-to-right sum (:149); nothing is stored
+    double norm = 0.0;
+    for (int c = 0; c < K; c += 64)
+        norm = wave_sum_in_order(ws, norm, (c + lane < K) ? step_weight(a, ws, src, base, c + lane) : 0.0, min(64, K - c), lane);
+    norm = unid(norm);
+    N2V_STAMP(1);
+    if (norm == 0.0) return false;
+    // ---- 3. the same weights again, q = K * (u / norm) (:150, :253), {k, q} onto the stack q selects (:252-257)
+    const double Kd = (double)K;
+    int ns = 0, nl = 0;
+    for (int c = 0; c < K; c += 64) {
+        const int k = c + lane;
+        const bool valid = k < K;
+        double qk = 0.0;
+        if (valid) qk = Kd * (step_weight(a, ws, src, base, k) / norm);
+        const bool is_small = valid && (qk < 1.0);
+        const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        if (valid) {
+            const int pos = is_small ? ns + __popcll(ms & below) : K - (nl + __popcll(ml & below) + 1);
+            S.idx[pos] = k;
+            S.q[pos] = qk;
+        }
+        ns += __popcll(ms);
+        nl += __popcll(ml);
+    }
+    ns = uni(ns);
+    nl = uni(nl);
+    wave_sync();
+    N2V_STAMP(2);
+    // ---- 4. pairing (:259-268); finished slots leave through the queue
+    wave_pair(S, sink, K, ns, nl, lane);
+    sink.finish();
+    N2V_STAMP(3);
+    return true;
 }
 
 }  // namespace n2v

@@ -32,7 +32,8 @@ SIGNATURES = {
     "n2v_build_edge_tables": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _f64, _f64, _i32, _ptr, _ptr, _i64, _i64,
                                         _ptr, _ptr, _ptr]),
     "n2v_build_edge_tables_wave": (C.c_int, [_i64, _ptr, _ptr, _ptr, _ptr, _f64, _f64, _i32, _ptr, _ptr, _i64, _i64,
-                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+                                             _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr]),
+    "n2v_edge_tables_wave_scratch_bytes": (C.c_int64, [_i64]),
     "n2v_build_edge_recs": (C.c_int, [_i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr]),
     "n2v_walk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _ptr, _ptr,
                            _u64, _ptr, _ptr, _ptr]),

@@ -126,6 +126,9 @@ class WalkEngine:
                 if builder == "lane":        # one lane per table: lanes of a wave should get tables of similar size
                     order = torch.argsort(kdst, descending=True).to(torch.int32)
                 work = torch.zeros(2, dtype=torch.int64, device=d)
+                # per-wave stacks of the tables that do not fit the wave's LDS slots (C3: 0.8 GB for max degree 16 614)
+                sbytes = int(self.lib.n2v_edge_tables_wave_scratch_bytes(self.max_degree)) if builder == "wave" else 0
+                scratch = torch.empty(max(sbytes, 64) // 8, dtype=torch.int64, device=d)
                 tick("src_of")
                 if want_thin:
                     if builder == "lane":
@@ -137,7 +140,8 @@ class WalkEngine:
                         _lib.check(self.lib.n2v_build_edge_tables_wave(
                             N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
                             self.p, self.q, sym, _lib.ptr(self.edge_off), None, 0, nnz, None,
-                            _lib.ptr(self.edge_slots), None, _lib.ptr(status), work[0:].data_ptr(), self._stream()))
+                            _lib.ptr(self.edge_slots), None, _lib.ptr(status), work[0:].data_ptr(), self.max_degree,
+                            _lib.ptr(scratch), sbytes, self._stream()))
                     tick("edge_tables_thin")
                 if want_fat:
                     if builder == "lane":
@@ -149,9 +153,10 @@ class WalkEngine:
                         _lib.check(self.lib.n2v_build_edge_tables_wave(
                             N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
                             self.p, self.q, sym, _lib.ptr(self.edge_off), None, 0, nnz, _lib.ptr(self.recs),
-                            None, _lib.ptr(self.edge_fat), _lib.ptr(status), work[1:].data_ptr(), self._stream()))
+                            None, _lib.ptr(self.edge_fat), _lib.ptr(status), work[1:].data_ptr(), self.max_degree,
+                            _lib.ptr(scratch), sbytes, self._stream()))
                     tick("edge_tables_fat")
-                del order, src_of, kdst
+                del order, src_of, kdst, scratch
             if want_fat and nnz > 0:
                 self.node_fat = torch.empty((max(nnz, 1), 4), dtype=torch.int64, device=d)
                 _lib.check(self.lib.n2v_build_fat_slots(
