@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--allow-out-of-band", action="store_true",
                     help="permit modes measured outside the +-0.002 AUC band (--merge hot at this size, an explicit lossy "
                          "--update-mode on a short corpus); the default line never needs it")
+    ap.add_argument("--merge-timers", action="store_true",
+                    help="N > 1, --merge tsum: time the merges with events (runs the eager Python loop instead of replaying "
+                         "the captured HIP graph of a base interval: slower, but merge_seconds is measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shared-negatives", action="store_true", help="skip the extra opt-in SGNS variant pass")
     ap.add_argument("--no-reference-exact", action="store_true", help="skip the extra reference-exact walk pass")
@@ -283,6 +286,13 @@ def main():
     torch.cuda.synchronize()
     t_pre = time.perf_counter() - t0
     eng = g._engine
+    t_pre_alloc = float(getattr(eng, "alloc_seconds", 0.0))    # host time of the table allocation (driver-side; see engine.py)
+    # a second call: the tables come back from the allocator's cache, what remains is index plumbing + the kernels
+    t0 = time.perf_counter()
+    g.preprocess_transition_probs()
+    torch.cuda.synchronize()
+    t_pre_warm = time.perf_counter() - t0
+    eng = g._engine
     if rank == 0:
         log("[bench] %s: graph %.1fs, preprocess %.2fs (%d alias slots, %.1f GB of %s slots)" % (
             args.config, t_graph, t_pre, eng.total_slots, eng.total_slots * (32 if eng.edge_fat is not None else 16) / 1e9,
@@ -314,14 +324,24 @@ def main():
 
     merge_secs = {"merge": 0.0, "wait": 0.0, "n": 0}
 
+    graph_mode = {"replays": 0}
+
     def sgns_step(step_no, timed=False):
+        # tsum: the merges are timed only on request — timing them needs the eager loop; by default a base interval is
+        # replayed from a captured HIP graph (n2v_hip/sgns.py:_train_tsum)
+        timed = timed and (args.merge != "tsum" or args.merge_timers)
         mg = sgns.train(model, walks, lens, epochs=1, comm=comm, n_walks_global=n_global, shard_offset=shard_offset,
                         syncs_per_epoch=syncs if args.merge != "tsum" else "auto", merge=args.merge,
                         overlap=not args.no_overlap, timers=timed)
+        if mg is not None:
+            graph_mode["replays"] = int(getattr(mg, "graph_replays", 0))
+            graph_mode["merges"] = mg.n_merges if isinstance(mg.n_merges, int) else sum(mg.n_merges)
         if timed and mg is not None:
             if mergers:
                 mergers[-1].release()       # keep the timers, not 2.5 GB of snapshots per timed step
             mergers.append(mg)
+        elif mg is not None:
+            mg.release()
 
     mergers = []
 
@@ -468,13 +488,20 @@ def main():
                  "table_layout": "fat (32-B slots)" if eng.edge_fat is not None else "thin (16-B slots + records)"},
         "walk_reference_exact": exact,
         "sgns_shared_negatives": shared,
-        "preprocess_seconds": t_pre, "alias_slots": eng.total_slots,
+        # first call in this process, of which the table allocation (hipMalloc, host-blocking when the driver hands out
+        # memory some allocation has just released), the rest (kernels + index plumbing), and a second call on the
+        # same graph (tables reused from the allocator's cache)
+        "preprocess_seconds": t_pre, "preprocess_alloc_seconds": t_pre_alloc,
+        "preprocess_kernel_seconds": t_pre - t_pre_alloc, "preprocess_seconds_second_call": t_pre_warm,
+        "alias_slots": eng.total_slots,
         # N > 1 (rank 0's timers): seconds per step the compute stream spent in the merge phases, of which waiting
         # for the cold rows' all-reduce; overlap_fraction = share of that all-reduce's stand-alone cost that was
         # hidden under training
         "merge_seconds": merge_secs["merge"] / K if world > 1 else None,
         "merge_wait_seconds": merge_secs["wait"] / K if world > 1 else None,
-        "merges_per_step": merge_secs["n"] / K if world > 1 else None,
+        "merges_per_step": (merge_secs["n"] / K if merge_secs["n"] else graph_mode.get("merges")) if world > 1 else None,
+        # tsum without --merge-timers: one base interval captured as a HIP graph and replayed this many times per pass
+        "merge_graph_replays_per_step": graph_mode["replays"] if world > 1 else None,
         "allreduce_seconds_standalone": comm_probe,
         # tsum merges are synchronous (pack -> all-reduce -> apply between two training launches): nothing is hidden
         "overlap_fraction": (None if not comm_probe else 0.0 if args.merge == "tsum" else

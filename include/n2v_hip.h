@@ -268,6 +268,23 @@ int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, i
                    unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
                    int32_t walk_splits, void* stream);
 
+/* The same launch with its walk range read from DEVICE memory, so that a captured launch (hipGraph) can be replayed for
+ * every merge interval of a pass (the tiered merges issue ~15 000 short launches per pass at 8 GPUs; replayed from a
+ * graph they cost no host time).  walks / lens: this rank's whole shard (n_local walks).  interval_state: device
+ * int64[2] = {base interval index c, sentences of earlier epochs E}; the launch is sub-interval
+ * s = c * subs_per_interval + sub_index of the n_sub_total the pass is cut into and trains the local walks
+ * [s * n_local / n_sub_total, (s+1) * n_local / n_sub_total) with sentences_base = E + begin * sentences_step and
+ * walk_id_base = E + shard_offset + begin — what n2v_sgns_train is given by the eager driver.  The caller advances
+ * interval_state between replays (in stream order).  Other arguments as n2v_sgns_train.                      */
+int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, int64_t n_local, int32_t walk_stride,
+                        float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                        int32_t window, int32_t negative, const uint32_t* sample_int,
+                        const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
+                        float min_alpha, int64_t sentences_step, int64_t sentences_total, int64_t alpha_batch,
+                        uint64_t seed, unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
+                        int32_t walk_splits, const int64_t* interval_state, int32_t sub_index,
+                        int32_t subs_per_interval, int64_t n_sub_total, int64_t shard_offset, void* stream);
+
 /* ---- replica merges of the multi-GPU trainer (no counterpart in the reference, whose gensim
  * threads share one table: src/main.py:87 `workers=`) ------------------------------------------------------
  * One process per GPU trains a replica x of a table on its shard; `base` is the copy all ranks agree on.  At

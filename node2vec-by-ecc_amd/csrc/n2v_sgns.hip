@@ -58,7 +58,26 @@ struct SgnsArgs {
     int32_t lpad;
     int32_t splits;   // wavefronts per walk (>= 1): split s trains the centres [s*n/S, (s+1)*n/S) of the sentence
     int32_t predraw;  // 1: all negatives of a centre are drawn by the lanes in parallel before its pairs (short launches)
+    // span mode (n2v_sgns_train_span): which walks this launch trains is read from device memory, so that a captured
+    // launch can be replayed for every merge interval of a pass
+    const int64_t* dyn;          // NULL, or {base interval index, sentences of earlier epochs}
+    int32_t dyn_sub, dyn_subs;   // this launch is sub-interval dyn_sub of dyn_subs per base interval
+    int64_t dyn_n_sub_total, dyn_n_local, dyn_shard_offset;
 };
+
+// span mode: sub-interval s = interval * subs + sub of the pass covers the local walks [s*n/k, (s+1)*n/k) (the cut of
+// n2v_hip/merge.py:chunk_plan); the schedule arguments follow as in the eager driver (n2v_hip/sgns.py:_train_tsum)
+__device__ __forceinline__ void resolve_span(SgnsArgs& a) {
+    if (!a.dyn) return;
+    const int64_t epoch_base = a.dyn[1];
+    const int64_t s = a.dyn[0] * a.dyn_subs + a.dyn_sub;
+    const int64_t b = s * a.dyn_n_local / a.dyn_n_sub_total, e = (s + 1) * a.dyn_n_local / a.dyn_n_sub_total;
+    a.n_walks = e - b;
+    a.walks += b * a.walk_stride;
+    if (a.lens) a.lens += b;
+    a.sent_base = epoch_base + b * a.sent_step;
+    a.walk_id_base = (uint64_t)(epoch_base + a.dyn_shard_offset + b);
+}
 
 // x -> x advanced by k steps of the sentence's 48-bit LCG (composition of the affine map by squaring)
 __device__ __forceinline__ uint64_t lcg_skip(uint64_t x, uint64_t k) {
@@ -240,7 +259,9 @@ __device__ __forceinline__ void add_row(float* base, int64_t row, int stride, in
 
 // G = target slots in use per group of 8 (6 when negative == 5: the centre + 5 draws)
 template <int VPL, int G, int MODE>
-__global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
+__global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a_in) {
+    SgnsArgs a = a_in;
+    resolve_span(a);
     extern __shared__ int32_t smem[];
     const int lane = threadIdx.x & 63;
     // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from
@@ -454,7 +475,9 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a) {
 // pair touches memory only for its context row: ~0.8 KB instead of 3.1 KB of atomic traffic.
 // Same update rule per (pair, target); different (correlated) negative samples.  negative <= 7.
 template <int VPL, int MODE>
-__global__ void __launch_bounds__(256) sgns_shared_kernel(SgnsArgs a) {
+__global__ void __launch_bounds__(256) sgns_shared_kernel(SgnsArgs a_in) {
+    SgnsArgs a = a_in;
+    resolve_span(a);
     extern __shared__ int32_t smem[];
     const int lane = threadIdx.x & 63;
     // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from
@@ -691,14 +714,21 @@ int predraw_mode(int walk_splits, int negative) {
 }
 }  // namespace
 
-extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
-                              float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
-                              int32_t window, int32_t negative, const uint32_t* sample_int,
-                              const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
-                              float min_alpha, int64_t sentences_base, int64_t sentences_step,
-                              int64_t sentences_total, int64_t alpha_batch,
-                              uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
-                              int32_t update_mode, int32_t max_blocks, int32_t walk_splits, void* stream) {
+namespace {
+struct SpanSpec {                // n2v_sgns_train_span; dyn == NULL: an ordinary launch
+    const int64_t* dyn;
+    int32_t sub, subs;
+    int64_t n_sub_total, n_local, shard_offset;
+};
+
+int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
+                float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                int32_t window, int32_t negative, const uint32_t* sample_int,
+                const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
+                float min_alpha, int64_t sentences_base, int64_t sentences_step,
+                int64_t sentences_total, int64_t alpha_batch,
+                uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
+                int32_t update_mode, int32_t max_blocks, int32_t walk_splits, const SpanSpec& span, void* stream) {
     if (walk_splits < 1 || walk_splits > walk_stride)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_splits %d outside [1, %d]", (int)walk_splits, (int)walk_stride);
     if (n_walks < 0 || walk_stride < 1 || n_words < 1 || dim < 1 || window < 1 || negative < 0 || negative > 64)
@@ -738,6 +768,8 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
     a.lpad = (walk_stride + 63) & ~63;
     a.splits = walk_splits;
     a.predraw = predraw_mode(walk_splits, negative);
+    a.dyn = span.dyn; a.dyn_sub = span.sub; a.dyn_subs = span.subs;
+    a.dyn_n_sub_total = span.n_sub_total; a.dyn_n_local = span.n_local; a.dyn_shard_offset = span.shard_offset;
     const size_t shmem = (size_t)4 * a.lpad * sizeof(int32_t);
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks * walk_splits + 3) / 4;
@@ -765,5 +797,41 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
         default:
             return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: row_stride %d must be 64, 128, 256 or 512", (int)row_stride);
     }
-    return n2v::check_launch("n2v_sgns_train");
+    return n2v::check_launch(who);
+}
+}  // namespace
+
+extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
+                              float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                              int32_t window, int32_t negative, const uint32_t* sample_int,
+                              const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
+                              float min_alpha, int64_t sentences_base, int64_t sentences_step,
+                              int64_t sentences_total, int64_t alpha_batch,
+                              uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
+                              int32_t update_mode, int32_t max_blocks, int32_t walk_splits, void* stream) {
+    return sgns_launch("n2v_sgns_train", walks, lens, n_walks, walk_stride, syn0, syn1neg, n_words, dim, row_stride, window,
+                       negative, sample_int, cum_table, lut, lut_bits, alpha, min_alpha, sentences_base, sentences_step,
+                       sentences_total, alpha_batch, seed, walk_id_base, pair_count, update_mode, max_blocks, walk_splits,
+                       SpanSpec{nullptr, 0, 1, 1, 0, 0}, stream);
+}
+
+extern "C" int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, int64_t n_local, int32_t walk_stride,
+                                   float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
+                                   int32_t window, int32_t negative, const uint32_t* sample_int,
+                                   const uint32_t* cum_table, const uint32_t* lut, int32_t lut_bits, float alpha,
+                                   float min_alpha, int64_t sentences_step, int64_t sentences_total, int64_t alpha_batch,
+                                   uint64_t seed, unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
+                                   int32_t walk_splits, const int64_t* interval_state, int32_t sub_index,
+                                   int32_t subs_per_interval, int64_t n_sub_total, int64_t shard_offset, void* stream) {
+    if (!interval_state || subs_per_interval < 1 || sub_index < 0 || sub_index >= subs_per_interval || n_sub_total < subs_per_interval ||
+        (n_sub_total % subs_per_interval) != 0 || n_local < 0 || shard_offset < 0)
+        return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train_span: bad span (sub %d of %d, %lld sub-intervals, %lld walks)",
+                         (int)sub_index, (int)subs_per_interval, (long long)n_sub_total, (long long)n_local);
+    // the launch is sized for the longest sub-interval (they differ by at most one walk); the kernel reads its own range
+    const int64_t max_walks = (n_local + n_sub_total - 1) / n_sub_total;
+    if (max_walks == 0) return N2V_OK;
+    return sgns_launch("n2v_sgns_train_span", walks, lens, max_walks, walk_stride, syn0, syn1neg, n_words, dim, row_stride, window,
+                       negative, sample_int, cum_table, lut, lut_bits, alpha, min_alpha, 0, sentences_step, sentences_total,
+                       alpha_batch, seed, 0, pair_count, update_mode, max_blocks, walk_splits,
+                       SpanSpec{interval_state, sub_index, subs_per_interval, n_sub_total, n_local, shard_offset}, stream);
 }

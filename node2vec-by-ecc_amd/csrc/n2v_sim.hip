@@ -41,7 +41,8 @@ sim_prepare_kernel(const float* __restrict__ vec, int stride, int dim, const int
     s = wave_sum(s);
     if (method == N2V_SIM_COS) {
         s2 = wave_sum(s2);
-        const float inv = 1.0f / sqrtf(s2);                       // gensim unitvec: scal(1/nrm2, x)
+        // gensim unitvec: scal(1/nrm2, x) if nrm2 > 0 else x — a zero row stays zero (similarity 0), not NaN
+        const float inv = s2 > 0.f ? 1.0f / sqrtf(s2) : 1.0f;
         for (int k = lane; k < dpad; k += 64) o[k] = k < dim ? x[k] * inv : 0.f;
     } else if (method == N2V_SIM_PEARSON) {
         const float mean = s / (float)dim;                        // scipy pearsonr: xm = x - mean; xm / norm(xm)

@@ -62,6 +62,7 @@ class _Comm(sgns._ProcessGroupComm):
     def __init__(self, host_staged):
         super().__init__()
         self.host_staged = host_staged
+        self.graph_capturable = not host_staged        # the gloo rehearsal goes through host memory: eager only
         # over RCCL the replicas' changes travel as bfloat16 (half the bytes of every merge; AUC unchanged to 2e-4
         # on both probe graphs at 2 and 8 replicas); the gloo rehearsal path stays fp32 (gloo has no bf16 sum)
         self.wire_dtype = None if host_staged else torch.bfloat16

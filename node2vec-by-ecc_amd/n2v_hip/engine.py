@@ -90,11 +90,17 @@ class WalkEngine:
             # multi-GB allocation that follows such a kernel takes seconds (tools/alloc_probe.py: 58 GB in 0.000 s
             # as the first thing, 3.06 s after a torch.argsort of 2e7 keys; round 1's preprocess spent 1.5-2.4 s of
             # its 2.76 s there).  The slot count comes from host arithmetic on the CSR for the same reason.
+            import time as _time
+            t_alloc = _time.perf_counter()
             if not self.first_order:
                 if want_thin:
                     self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
                 if want_fat:
                     self.edge_fat = torch.empty((max(total, 1), 4), dtype=torch.int64, device=d)
+            # host time of the table allocation (hipMalloc blocks the host when the driver has to hand out memory another
+            # allocation has just released: 65-80 ms per GiB, tools/alloc_probe2.py; ~0 from the allocator's cache or
+            # from memory that was never used) — reported separately from the kernels by bench.py
+            self.alloc_seconds = _time.perf_counter() - t_alloc
             tick("alloc")
             status = torch.zeros(1, dtype=torch.int32, device=d)
             self.node_slots = torch.zeros((max(nnz, 1), 2), dtype=torch.int64, device=d)

@@ -225,6 +225,30 @@ class SgnsModel:
                              sentences_total, walk_id_base, 0, splits, _lib.stream_ptr(dev))
         return launch
 
+    def span_launcher(self, walks, lens, sentences_total, sentences_step, interval_state, subs_per_interval, n_sub_total,
+                      shard_offset, splits):
+        """-> launch(sub_index): n2v_sgns_train_span over this rank's whole shard — the walk range comes from the device
+        word pair `interval_state` (int64[2]: base interval index, sentences of earlier epochs), so a captured launch
+        can be replayed for every base interval of a pass (the graph path of the tiered merges)."""
+        assert walks.dtype == torch.int32 and walks.is_contiguous() and walks.device == self.device
+        assert interval_state.dtype == torch.int64 and interval_state.numel() == 2 and interval_state.device == self.device
+        n_local, L = int(walks.shape[0]), int(walks.shape[1])
+        max_walks = -(-n_local // int(n_sub_total))
+        if splits == "auto":
+            splits = max(1, min(L, -(-8192 // max(max_walks, 1))))
+        mode = launch_update_mode(self.update_mode, self._auto_mode, splits, self.allow_out_of_band)
+        dev = self.device
+
+        def launch(sub_index):
+            _lib.check(self.lib.n2v_sgns_train_span(
+                _lib.ptr(walks), _lib.ptr(lens), n_local, L, _lib.ptr(self.syn0), _lib.ptr(self.syn1neg), self.n_words,
+                self.dim, self.stride, self.window, self.negative, _lib.ptr(self.sample_int), _lib.ptr(self.cum_table),
+                _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha, int(sentences_step), int(sentences_total),
+                max(1, MAX_WORDS_IN_BATCH // L), self.seed & (2**64 - 1), _lib.ptr(self.pair_count), mode, 0, int(splits),
+                _lib.ptr(interval_state), int(sub_index), int(subs_per_interval), int(n_sub_total), int(shard_offset),
+                _lib.stream_ptr(dev)))
+        return launch
+
     def pairs_trained(self):
         return int(self.pair_count.item())
 
@@ -242,6 +266,7 @@ class _ProcessGroupComm:
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.graph_capturable = str(dist.get_backend(group)) == "nccl"     # RCCL collectives can be captured into a HIP graph
 
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -279,19 +304,35 @@ def _tsum_setup(model, L, n_walks_global, world, syncs_per_epoch):
     return n_chunks, plan
 
 
-def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops, timers=False):
+def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops, timers=False,
+                graph="auto", splits="auto"):
     """merge="tsum": pure sums at per-row cadences (SumTierPlan).  The pass is cut into base intervals x sub-intervals;
     after every sub-interval the tiers that are due are merged.  Meets the AUC band at every graph size in simulation
     (DESIGN.md 6), but the launches between two hub-tier merges are short (n_local / (n_chunks * 64) walks): the
-    price of synchronous hub tiers with one wavefront per walk."""
+    price of synchronous hub tiers with one wavefront per walk.  On a GPU the [train, pack, all-reduce, apply] x sub
+    sequence of ONE base interval is captured into a HIP graph (the merge pattern repeats every base interval; the
+    training launches read their walk range from a device counter) and replayed n_chunks times per pass — ~15 000
+    short launches per pass at 8 GPUs then cost no host time (graph=False / timers=True: the eager loop)."""
     n_local = int(walks.shape[0])
     world = comm.world
     total = epochs * n_walks_global
     n_chunks, plan = _tsum_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch)
     merger = TieredSumMerger([model.syn0, model.syn1neg], plan, comm, ops=ops, timed=timers)
+    use_graph = (graph is not False and not timers and model.device.type == "cuda" and hasattr(model, "span_launcher")
+                 and getattr(comm, "graph_capturable", True) and merger.fused)
+    if use_graph:
+        try:
+            _train_tsum_graph(model, walks, lens, epochs, world, n_walks_global, shard_offset, n_chunks, plan, merger, total,
+                              splits)
+            return merger
+        except _GraphCaptureFailed as e:
+            if graph is True:
+                raise
+            import warnings
+            warnings.warn("tiered merges: HIP graph capture failed (%s); running the eager loop" % (e,))
     subs = chunk_plan(n_local, n_chunks * plan.sub, exact=True)
     due = [plan.level_due(c) for c in range(len(subs))]
-    launch = model.span_trainer(walks, lens, sentences_total=total, sentences_step=world, splits="auto")
+    launch = model.span_trainer(walks, lens, sentences_total=total, sentences_step=world, splits=splits)
     # (the host-logic tests drive this loop with a stand-in model on CPU tensors)
     with (torch.cuda.device(model.device) if model.device.type == "cuda" else contextlib.nullcontext()):
         for ep in range(epochs):
@@ -299,6 +340,44 @@ def _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, 
                 launch(b, e, ep * n_walks_global + b * world, ep * n_walks_global + shard_offset + b)
                 if due[c] is not None:
                     merger.merge(due[c])
+    return merger
+
+
+class _GraphCaptureFailed(RuntimeError):
+    pass
+
+
+def _train_tsum_graph(model, walks, lens, epochs, world, n_walks_global, shard_offset, n_chunks, plan, merger, total, splits):
+    """One base interval as a HIP graph, replayed n_chunks x epochs times.  Nothing is trained during capture; a failed
+    capture leaves the tables untouched (the caller falls back to the eager loop)."""
+    dev = model.device
+    sub = plan.sub
+    due = [plan.level_due(j) for j in range(sub)]            # periodic in the base interval
+    with torch.cuda.device(dev):
+        state = torch.zeros(2, dtype=torch.int64, device=dev)       # {base interval, sentences of earlier epochs}
+        step = torch.tensor([1, 0], dtype=torch.int64, device=dev)
+        launch = model.span_launcher(walks, lens, total, world, state, sub, n_chunks * sub, shard_offset, splits)
+        n_before = list(merger.n_merges)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        try:
+            with torch.cuda.graph(g):
+                for j in range(sub):
+                    launch(j)
+                    if due[j] is not None:
+                        merger.merge(due[j])
+                state.add_(step)
+        except Exception as e:          # capture is all-or-nothing: nothing has run
+            merger.n_merges = n_before
+            raise _GraphCaptureFailed("%s: %s" % (type(e).__name__, e))
+        per_interval = [a - b for a, b in zip(merger.n_merges, n_before)]
+        for ep in range(epochs):
+            state.copy_(torch.tensor([0, ep * n_walks_global], dtype=torch.int64), non_blocking=False)
+            for _ in range(n_chunks):
+                g.replay()
+        merger.n_merges = [b + k * n_chunks * epochs for b, k in zip(n_before, per_interval)]
+        merger.graph_replays = n_chunks * epochs
+        torch.cuda.current_stream(dev).synchronize()      # the graph and its buffers go out of scope with this frame
     return merger
 
 
@@ -314,7 +393,7 @@ def check_merge_in_band(merge, n_words, allow_out_of_band=False):
 
 
 def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_offset=0, syncs_per_epoch="auto",
-          merge="tsum", overlap=True, cold_delay=False, ops=None, timers=False):
+          merge="tsum", overlap=True, cold_delay=False, ops=None, timers=False, graph="auto", splits="auto"):
     """Train `epochs` passes over this rank's walks.  With a communicator the replicas are merged: merge="tsum"
     (default) by pure sums at per-row cadences (TieredSumMerger) — the scheme that stays inside the AUC band at
     every graph size measured —, merge="hot" by per-row-weighted sums at `syncs_per_epoch` merges per pass
@@ -333,7 +412,8 @@ def train(model, walks, lens, epochs=1, comm=None, n_walks_global=None, shard_of
         return None
     check_merge_in_band(merge, model.n_words, getattr(model, "allow_out_of_band", False))
     if merge == "tsum":
-        return _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops, timers)
+        return _train_tsum(model, walks, lens, epochs, comm, n_walks_global, shard_offset, syncs_per_epoch, ops, timers,
+                           graph=graph, splits=splits)
     n_chunks, plan = _merge_setup(model, int(walks.shape[1]), n_walks_global, world, syncs_per_epoch, merge, cold_delay)
     merger = ReplicaMerger([model.syn0, model.syn1neg], plan, comm, overlap=overlap, ops=ops)
     chunks = chunk_plan(n_local, n_chunks, exact=True)

@@ -227,7 +227,14 @@ class Graph():
         self._check_popwalk()
         if self.p == 0 or self.q == 0:
             raise ZeroDivisionError("float division by zero")
-        eng = WalkEngine(self._csr, self.p, self.q, device=self.device)
+        # the engine (graph on the device) is reused when p, q and the graph are unchanged, and its tables are released
+        # BEFORE the new ones are allocated: the 58.5 GB of C3 then come back from the allocator's cache instead of a
+        # second hipMalloc beside the old ones (1.5 s on this stack when the driver has to hand out recently freed
+        # memory: tools/alloc_probe2.py)
+        eng = self._engine
+        if eng is None or eng.csr is not self._csr or eng.p != float(self.p) or eng.q != float(self.q):
+            self._engine = eng = None
+            eng = WalkEngine(self._csr, self.p, self.q, device=self.device)
         eng.preprocess()
         self._engine = eng
         self.alias_nodes = _AliasNodes(self)

@@ -105,7 +105,8 @@ def test_bench_two_ranks_strong_scaling_reports_merge_timers(tmp_path):
     port = 29100 + os.getpid() % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2",
-           "--rounds", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo", "--merge", "hot"]
+           "--rounds", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo", "--merge", "hot",
+           "--allow-out-of-band"]          # 100 000 rows: merge=hot is fenced above 32 768 (n2v_hip/sgns.py)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -127,7 +128,8 @@ def test_bench_two_ranks_tiered_sum_merges(tmp_path):
     port = 29050 + os.getpid() % 40
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2",
-           "--rounds", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--backend", "gloo", "--merge", "tsum"]
+           "--rounds", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--backend", "gloo", "--merge", "tsum",
+           "--merge-timers"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

@@ -496,6 +496,67 @@ def test_main_link_flow_with_user_edges(torch_cuda):
     print("user edges: %d added, AUC %.4f -> %.4f" % (res["edges_added"], res["roc"], res["roc_user"]))
 
 
+def test_tiered_merges_graph_replay_equals_eager_loop(torch_cuda):
+    """The default multi-GPU path replays ONE captured base interval of the tiered merges ([train, pack, all-reduce,
+    apply] x sub-intervals; the training launches read their walk range from a device counter) instead of issuing
+    ~15 000 launches per pass from Python.  With one walk per launch on one wavefront the run is sequential, so the
+    replayed graph must leave bit-identical tables, pair counts and merge counts — through a real RCCL all-reduce
+    (one-rank group standing in for a world of four: what the collective returns for one rank is its input)."""
+    torch = torch_cuda
+    import os
+    import torch.distributed as dist
+    from n2v_hip import sgns
+    from n2v_hip import dist as n2v_dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    had = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29910 + os.getpid() % 40)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        comm = n2v_dist._Comm(False)
+        comm.world = 4                                   # plan the merges of a 4-GPU job; the wire is the one-rank group
+        assert comm.graph_capturable and comm.wire_dtype == torch.bfloat16
+        rs = np.random.RandomState(4)
+        n_words, L, epochs = 1500, 24, 2
+        p = rs.pareto(1.1, n_words) + 0.05
+        p /= p.sum()
+        probe = sgns.SgnsModel(n_words, dim=64, seed=5)
+        results = []
+        walks = None
+        for graph in (False, True):
+            m = sgns.SgnsModel(n_words, dim=64, window=5, negative=5, seed=5)
+            if walks is None:
+                # a corpus with exactly one walk per sub-interval: counts first (they fix the tier plan), then the size
+                big = rs.choice(n_words, size=(4096, L), p=p).astype(np.int32)
+                counts = np.bincount(big.reshape(-1), minlength=n_words)
+                m.build_vocab(counts=counts)
+                n_chunks, plan = sgns._tsum_setup(m, L, 4096 * 4, 4, 3)
+                assert plan.n_tiers >= 2 and n_chunks == 3
+                n_local = n_chunks * plan.sub
+                walks = torch.from_numpy(big[:n_local].copy()).cuda()
+            else:
+                m.build_vocab(counts=counts)
+            mg = sgns.train(m, walks, None, epochs=epochs, comm=comm, n_walks_global=4096 * 4, shard_offset=4096,
+                            syncs_per_epoch=3, merge="tsum", graph=graph, splits=1)
+            torch.cuda.synchronize()
+            assert (getattr(mg, "graph_replays", 0) == 3 * epochs) == graph
+            results.append((m.syn0.clone(), m.syn1neg.clone(), m.pairs_trained(), list(mg.n_merges),
+                            [b.clone() for b in mg.base]))
+        e, g = results
+        assert e[2] == g[2] > 0 and e[3] == g[3] and sum(e[3]) == 3 * epochs * plan.sub
+        assert torch.equal(e[0], g[0]) and torch.equal(e[1], g[1])
+        assert all(torch.equal(a, b) for a, b in zip(e[4], g[4]))
+        assert torch.equal(g[0], g[4][0])               # after the last (full) merge the table IS the agreed copy
+    finally:
+        dist.destroy_process_group()
+        for k, v in had.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_rccl_path_of_the_merges_single_rank(torch_cuda):
     """The exact calls the multi-GPU merges make over RCCL (bf16 / fp32 wire formats, gathered hot rows), on a
     one-rank process group: what the collective returns for one rank is its input, so the results are known."""
