@@ -107,8 +107,10 @@ int n2v_build_edge_tables_wave(int64_t n_nodes, const int64_t* row_ptr, const in
 
 /* Walk records.  edge_off == NULL: first-order shortcut (p == q == 1), every record
  * points at dst's node table, slot = slot_base + row_ptr[dst].  Otherwise
- * slot = slot_base + edge_off[e].  Host-side limit checks need `max_degree` and
- * `total_slots` (slot_base + last offset).                                              */
+ * slot = slot_base + edge_off[e]; edge_off[e] < 0 marks an entry whose table is NOT stored
+ * (slot = N2V_NO_TABLE: tables under a memory budget, n2v_walk_hybrid).  Host-side limit
+ * checks need `max_degree` and `total_slots` (slot_base + last offset).                  */
+#define N2V_NO_TABLE 0xFFFFFFFFFFULL /* 40-bit table index of a record whose table is rebuilt on the fly */
 int n2v_build_edge_recs(int64_t n_nodes, int64_t nnz, const int64_t* row_ptr, const int32_t* col,
                         const int64_t* edge_off, int64_t slot_base, int64_t max_degree,
                         int64_t total_slots, n2v_edge_rec* recs, void* stream);
@@ -215,6 +217,20 @@ int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double
                         const int64_t* walk_uoff, uint64_t seed, n2v_alias_slot* scratch,
                         int64_t scratch_slots, int32_t* walks, int32_t* lens, int32_t* status,
                         void* stream);
+
+/* Tables under a memory budget — the middle path between n2v_walk_fat and n2v_walk_on_the_fly (the reference's own
+ * answer to sum-of-deg^2 memory is to rebuild EVERY table per step, src/node2vec.py:34-53, src/settings.py:18).  The
+ * caller stores fat tables for a subset of the CSR entries (n2v_build_edge_recs with negative offsets for the others,
+ * n2v_build_edge_tables_wave over an `order` list of the stored ones); a step that arrives through a stored entry is
+ * one gather as in n2v_walk_fat, any other step rebuilds its table as n2v_walk_on_the_fly does.  Same walks, bit for
+ * bit.  One wavefront per walk.  node_fat: fat node tables (first step); fat / recs as for n2v_walk_fat; scratch as
+ * for n2v_walk_on_the_fly.                                                                                        */
+int n2v_walk_hybrid(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q, int32_t symmetric,
+                    int64_t max_degree, const struct n2v_fat_slot* node_fat, const struct n2v_fat_slot* fat,
+                    const n2v_edge_rec* recs, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+                    int64_t pos_count, int64_t round_begin, int64_t round_count, int32_t walk_length, int32_t rng_mode,
+                    const double* uniforms, const int64_t* walk_uoff, uint64_t seed, n2v_alias_slot* scratch,
+                    int64_t scratch_slots, int32_t* walks, int32_t* lens, int32_t* status, void* stream);
 
 /* ---- learn_embeddings (src/main.py:82-90 -> gensim 3.2.0 Word2Vec, sg=1, negative sampling) --
  * gensim is a third-party dependency absent from the reference tree (requirements.txt:17);

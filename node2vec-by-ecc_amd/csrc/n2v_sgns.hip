@@ -774,11 +774,15 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks * walk_splits + 3) / 4;
     // default grid: 256 CUs x 12 workgroups of 4 waves — every wave slot of the chip at this kernel's 36-40
-    // VGPRs (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096 8.0e8, 6144 8.3e8) — but never more
-    // than one wave per two vocabulary rows — beyond that the racing waves read each other's rows so stale that
-    // small graphs train measurably differently from the sequential algorithm
+    // VGPRs (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096 8.0e8, 6144 8.3e8) — but never more than one
+    // wavefront per 64 vocabulary rows: the racing waves read each other's rows stale, and the link-prediction AUC
+    // moves away from the sequential algorithm's in proportion to waves in flight per row.  Measured against the
+    // sequential comparator on a 131 019-row hub graph (tests/probes/grid_band_probe.py, profiles/r03/logs): 3072
+    // workgroups -0.0022 (atomic) / -0.0013 (agent), 1024 -0.0005 / -0.0008, 512 -0.0002 / -0.0002, 256 +0.0001 /
+    // -0.0001 — at the SAME pair rate down to 256 (atomic: bound by the float-atomic rate) / 768 (agent) workgroups.
+    // C3 (10^6 rows) keeps its 3072.
     int64_t cap = max_blocks > 0 ? max_blocks : 3072;
-    if (max_blocks <= 0 && cap > n_words / 8) cap = n_words / 8 > 0 ? n_words / 8 : 1;
+    if (max_blocks <= 0 && cap > n_words / 256) cap = n_words / 256 > 16 ? n_words / 256 : 16;
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);
 #define N2V_SGNS_LAUNCH_M(V, M)                                                            \

@@ -105,7 +105,9 @@ edge_recs_kernel(int64_t nnz, const int64_t* __restrict__ row_ptr, const int32_t
     if (e >= nnz) return;
     const int32_t dst = col[e];
     const int64_t b = row_ptr[dst], deg = row_ptr[dst + 1] - b;
-    const uint64_t slot = (uint64_t)(slot_base + (edge_off ? edge_off[e] : b));
+    const int64_t off = edge_off ? edge_off[e] : b;
+    // a negative offset: this entry's table is not stored (tables under a memory budget, n2v_walk_hybrid rebuilds it)
+    const uint64_t slot = off < 0 ? (uint64_t)N2V_NO_TABLE : (uint64_t)(slot_base + off);
     uint4 r;
     r.x = (uint32_t)slot;
     r.y = (uint32_t)b;
@@ -124,7 +126,7 @@ extern "C" int n2v_build_edge_recs(int64_t n_nodes, int64_t nnz, const int64_t* 
     if (nnz >= (int64_t)1 << 32) return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_recs: nnz %lld >= 2^32", (long long)nnz);
     if (max_degree >= (int64_t)1 << 24)
         return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_recs: max degree %lld >= 2^24", (long long)max_degree);
-    if (total_slots >= (int64_t)1 << 40)
+    if (total_slots >= (int64_t)N2V_NO_TABLE)
         return n2v::fail(N2V_ERR_INVALID, "n2v_build_edge_recs: %lld alias slots >= 2^40", (long long)total_slots);
     if (nnz == 0) return N2V_OK;
     hipLaunchKernelGGL(edge_recs_kernel, dim3(n2v::grid_for(nnz, 256)), dim3(256), 0, (hipStream_t)stream, nnz,

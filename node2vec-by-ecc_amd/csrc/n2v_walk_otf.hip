@@ -37,11 +37,16 @@ struct OtfArgs {
     uint64_t seed;
     n2v_alias_slot* scratch;  // [n_waves][max_degree]
     int64_t max_degree;
+    // hybrid (n2v_walk_hybrid): fat tables of a subset of the CSR entries; a record's table index N2V_NO_TABLE = rebuild
+    const n2v_fat_slot* node_fat;
+    const n2v_fat_slot* fat;
+    const n2v_edge_rec* recs;
     int32_t* walks;
     int32_t* lens;
     int32_t* status;
 };
 
+template <bool HYBRID>
 __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
     __shared__ n2v_alias_slot lds[4 * kLdsSlots];
     __shared__ double feed[4 * n2v::kFeed];
@@ -69,28 +74,57 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
         if (lane == 0) out[0] = cur;
         int32_t len = 1;
         bool failed = false;
+        // hybrid: the stored table of the step about to be taken (first step: the node table), or N2V_NO_TABLE
+        const n2v_fat_slot* arr = a.node_fat;
+        uint64_t tbl = HYBRID ? (uint64_t)uni64(a.g.row_ptr[cur]) : (uint64_t)N2V_NO_TABLE;
+        int K = HYBRID ? uni((int)(a.g.row_ptr[cur + 1] - a.g.row_ptr[cur])) : 0;
         for (; len < L; ++len) {
-            const int64_t base = uni64(a.g.row_ptr[cur]);
-            const int K = uni((int)(a.g.row_ptr[cur + 1] - base));
+            int64_t base = 0;
+            if (!HYBRID || tbl == (uint64_t)N2V_NO_TABLE) {
+                base = uni64(a.g.row_ptr[cur]);
+                K = uni((int)(a.g.row_ptr[cur + 1] - base));
+            }
             if (K == 0) break;  // dead end (:50-51)
-            bool ok;
-            ws.row_n = n2v::wave_cache_row(a.g, my_row, prev, lane);     // has_edge(nbr, prev): prev's row, staged in LDS
-            if (K <= kLdsSlots) ok = n2v::wave_build_table(a.g, Tl, ws, prev, base, K, lane);
-            else ok = n2v::wave_build_table(a.g, Tg, ws, prev, base, K, lane);
-            if (!ok) { failed = true; break; }
             double u1, u2;
             const uint32_t t = (uint32_t)(len - 1);
             if (a.rng_mode == N2V_RNG_UNIFORMS) { u1 = up[2 * (int64_t)t]; u2 = up[2 * (int64_t)t + 1]; }
             else n2v::philox_uniforms(a.seed, gw, t, u1, u2);
             const int kk = (int)(u1 * (double)K);  // :277
-            double qk; int Jk;
-            if (K <= kLdsSlots) { qk = Tl[kk].q; Jk = Tl[kk].J; }
-            else { qk = Tg[kk].q; Jk = Tg[kk].J; }
-            const int pick = (u2 < qk) ? kk : Jk;  // :278-281
-            prev = cur;
-            cur = uni(a.g.col[base + pick]);
+            if (HYBRID && tbl != (uint64_t)N2V_NO_TABLE) {
+                // stored table: one 32-B slot (every lane reads the same address), both outcomes' records inside
+                const uint4* sp = reinterpret_cast<const uint4*>(arr + tbl + (uint64_t)kk);
+                const uint4 lo = sp[0], hi = sp[1];
+                const double qk = __hiloint2double((int)lo.y, (int)lo.x);
+                const bool keep = u2 < qk;  // :278
+                const uint32_t slot_lo = keep ? lo.z : hi.y, deg_hi = keep ? lo.w : hi.z, dst = keep ? hi.x : hi.w;
+                prev = cur;
+                cur = uni((int32_t)dst);
+                tbl = ((uint64_t)(uint32_t)uni((int)(deg_hi >> 24)) << 32) | (uint32_t)uni((int)slot_lo);
+                K = uni((int)(deg_hi & 0xFFFFFFu));
+                arr = a.fat;
+            } else {
+                bool ok;
+                ws.row_n = n2v::wave_cache_row(a.g, my_row, prev, lane);     // has_edge(nbr, prev): prev's row, staged in LDS
+                if (K <= kLdsSlots) ok = n2v::wave_build_table(a.g, Tl, ws, prev, base, K, lane);
+                else ok = n2v::wave_build_table(a.g, Tg, ws, prev, base, K, lane);
+                if (!ok) { failed = true; break; }
+                double qk; int Jk;
+                if (K <= kLdsSlots) { qk = Tl[kk].q; Jk = Tl[kk].J; }
+                else { qk = Tg[kk].q; Jk = Tg[kk].J; }
+                const int pick = (u2 < qk) ? kk : Jk;  // :278-281
+                prev = cur;
+                if (HYBRID) {
+                    const uint4 r = *reinterpret_cast<const uint4*>(a.recs + base + pick);   // {slot_lo, base, dst, deg_hi}
+                    cur = uni((int32_t)r.z);
+                    tbl = ((uint64_t)(uint32_t)uni((int)(r.w >> 24)) << 32) | (uint32_t)uni((int)r.x);
+                    K = uni((int)(r.w & 0xFFFFFFu));
+                    arr = a.fat;
+                } else {
+                    cur = uni(a.g.col[base + pick]);
+                }
+                __builtin_amdgcn_wave_barrier();  // the table is rebuilt in place on the next step
+            }
             if (lane == 0) out[len] = cur;
-            __builtin_amdgcn_wave_barrier();  // the table is rebuilt in place on the next step
         }
         if (failed && lane == 0) atomicOr(a.status, N2V_STATUS_ZERO_NORM);
         if (lane == 0) {
@@ -102,37 +136,68 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
 
 }  // namespace
 
+namespace {
+int launch_otf(const char* who, bool hybrid, const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
+               int32_t symmetric, int64_t max_degree, const n2v_fat_slot* node_fat, const n2v_fat_slot* fat,
+               const n2v_edge_rec* recs, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+               int64_t pos_count, int64_t round_begin, int64_t round_count, int32_t walk_length,
+               int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
+               n2v_alias_slot* scratch, int64_t scratch_slots, int32_t* walks, int32_t* lens,
+               int32_t* status, void* stream) {
+    if (pos_count < 0 || round_count < 0 || pos_begin < 0 || round_begin < 0 || walk_length < 1 ||
+        pos_begin + pos_count > n_starts || max_degree < 0)
+        return n2v::fail(N2V_ERR_INVALID, "%s: bad shard or length", who);
+    const int64_t n_local = pos_count * round_count;
+    if (n_local == 0) return N2V_OK;
+    if (!row_ptr || !col || !starts || !walks || !lens || !status)
+        return n2v::fail(N2V_ERR_INVALID, "%s: null pointer", who);
+    if (hybrid && (!node_fat || !recs || (walk_length > 2 && !fat)))
+        return n2v::fail(N2V_ERR_INVALID, "%s: the stored tables and the walk records are needed", who);
+    if (hybrid && ((((uintptr_t)node_fat | (uintptr_t)fat) & 31) != 0))
+        return n2v::fail(N2V_ERR_INVALID, "%s: fat slots not 32-byte aligned", who);
+    if (!(p == p) || !(q == q) || p == 0.0 || q == 0.0)
+        return n2v::fail(N2V_ERR_INVALID, "%s: p and q must be non-zero numbers", who);
+    if (rng_mode != N2V_RNG_UNIFORMS && rng_mode != N2V_RNG_PHILOX)
+        return n2v::fail(N2V_ERR_INVALID, "%s: rng_mode %d", who, (int)rng_mode);
+    if (rng_mode == N2V_RNG_UNIFORMS && walk_length > 1 && !uniforms)
+        return n2v::fail(N2V_ERR_INVALID, "%s: parity mode needs a uniform buffer", who);
+    // grid: as many resident waves as the scratch rows allow (4 workgroups of 4 waves per CU by LDS)
+    int64_t blocks = (n_local + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;   // 40 KiB of LDS per workgroup: 4 per CU
+    if (max_degree > kLdsSlots) {
+        if (!scratch) return n2v::fail(N2V_ERR_INVALID, "%s: scratch needed (max degree %lld > %d)", who,
+                                       (long long)max_degree, kLdsSlots);
+        const int64_t fit = scratch_slots / max_degree / 4;
+        if (fit < 1) return n2v::fail(N2V_ERR_INVALID, "%s: scratch smaller than 4 x max_degree slots", who);
+        if (blocks > fit) blocks = fit;
+    }
+    OtfArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
+              rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, node_fat, fat, recs, walks, lens, status};
+    if (hybrid) hipLaunchKernelGGL(walk_otf_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(walk_otf_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return n2v::check_launch(who);
+}
+}  // namespace
+
 extern "C" int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
                                    int32_t symmetric, int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
                                    int64_t pos_count, int64_t round_begin, int64_t round_count, int32_t walk_length,
                                    int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
                                    n2v_alias_slot* scratch, int64_t scratch_slots, int32_t* walks, int32_t* lens,
                                    int32_t* status, void* stream) {
-    if (pos_count < 0 || round_count < 0 || pos_begin < 0 || round_begin < 0 || walk_length < 1 ||
-        pos_begin + pos_count > n_starts || max_degree < 0)
-        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: bad shard or length");
-    const int64_t n_local = pos_count * round_count;
-    if (n_local == 0) return N2V_OK;
-    if (!row_ptr || !col || !starts || !walks || !lens || !status)
-        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: null pointer");
-    if (!(p == p) || !(q == q) || p == 0.0 || q == 0.0)
-        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: p and q must be non-zero numbers");
-    if (rng_mode != N2V_RNG_UNIFORMS && rng_mode != N2V_RNG_PHILOX)
-        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: rng_mode %d", (int)rng_mode);
-    if (rng_mode == N2V_RNG_UNIFORMS && walk_length > 1 && !uniforms)
-        return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: parity mode needs a uniform buffer");
-    // grid: as many resident waves as the scratch rows allow (4 workgroups of 4 waves per CU by LDS)
-    int64_t blocks = (n_local + 3) / 4;
-    if (blocks > 256 * 4) blocks = 256 * 4;   // 40 KiB of LDS per workgroup: 4 per CU
-    if (max_degree > kLdsSlots) {
-        if (!scratch) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: scratch needed (max degree %lld > %d)",
-                                       (long long)max_degree, kLdsSlots);
-        const int64_t fit = scratch_slots / max_degree / 4;
-        if (fit < 1) return n2v::fail(N2V_ERR_INVALID, "n2v_walk_on_the_fly: scratch smaller than 4 x max_degree slots");
-        if (blocks > fit) blocks = fit;
-    }
-    OtfArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
-              rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, walks, lens, status};
-    hipLaunchKernelGGL(walk_otf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    return n2v::check_launch("n2v_walk_on_the_fly");
+    return launch_otf("n2v_walk_on_the_fly", false, row_ptr, col, w, p, q, symmetric, max_degree, nullptr, nullptr, nullptr, starts,
+                      n_starts, pos_begin, pos_count, round_begin, round_count, walk_length, rng_mode, uniforms, walk_uoff,
+                      seed, scratch, scratch_slots, walks, lens, status, stream);
+}
+
+extern "C" int n2v_walk_hybrid(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q, int32_t symmetric,
+                               int64_t max_degree, const n2v_fat_slot* node_fat, const n2v_fat_slot* fat,
+                               const n2v_edge_rec* recs, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
+                               int64_t pos_count, int64_t round_begin, int64_t round_count, int32_t walk_length,
+                               int32_t rng_mode, const double* uniforms, const int64_t* walk_uoff, uint64_t seed,
+                               n2v_alias_slot* scratch, int64_t scratch_slots, int32_t* walks, int32_t* lens,
+                               int32_t* status, void* stream) {
+    return launch_otf("n2v_walk_hybrid", true, row_ptr, col, w, p, q, symmetric, max_degree, node_fat, fat, recs, starts,
+                      n_starts, pos_begin, pos_count, round_begin, round_count, walk_length, rng_mode, uniforms, walk_uoff,
+                      seed, scratch, scratch_slots, walks, lens, status, stream);
 }

@@ -51,12 +51,13 @@ class WalkEngine:
         self.recs = None
         self.node_fat = self.edge_fat = None
         self.first_order = False
+        self.partial = False          # tables under a memory budget: only entries with deg(dst) <= stored_degree_cut
 
     # ------------------------------------------------------------------ tables
     def _stream(self):
         return _lib.stream_ptr(self.device)
 
-    def preprocess(self, first_order_shortcut=True, fat="auto", builder="wave"):
+    def preprocess(self, first_order_shortcut=True, fat="auto", builder="wave", budget_bytes=None):
         """preprocess_transition_probs (src/node2vec.py:176-204) on device.
 
         With p == q == 1 every (src,dst) table is bit-identical to dst's node table
@@ -67,7 +68,12 @@ class WalkEngine:
         thin and fat side by side).  The edge tables exist ONCE: the wave-per-table kernel writes the chosen
         layout directly; (J, q) of a stored fat table are recovered by `thin_view` for the dict-like views.
         builder: "wave" (n2v_build_edge_tables_wave) or "lane" (round 1's one-lane-per-table kernel, kept as a
-        cross-check of the same bits)."""
+        cross-check of the same bits).
+        budget_bytes: tables under a memory budget — the middle path between stored tables and the reference's
+        rebuild-every-step fallback (src/node2vec.py:34-53, src/settings.py:18).  If the fat edge tables exceed it,
+        only the tables of entries (src -> dst) with deg(dst) <= D are stored (D = the largest cut that fits: every
+        table is visited equally often per byte, but a rebuilt table costs a fixed latency on top of its slots, so the
+        small ones are the ones to keep); the walk (n2v_walk_hybrid) rebuilds the others per step.  Same walks."""
         csr, d = self.csr, self.device
         N, nnz = csr.n_nodes, csr.nnz
         self.timings = {}
@@ -76,6 +82,18 @@ class WalkEngine:
         with torch.cuda.device(d):
             self.first_order = bool(first_order_shortcut and self.p == 1.0 and self.q == 1.0)
             total = nnz if self.first_order else self.total_edge_slots
+            self.partial, self.stored_degree_cut, stored_entries = False, None, None
+            if budget_bytes is not None and not self.first_order and total * FAT_BYTES > int(budget_bytes):
+                # host arithmetic (no device reduction before the big allocation): slots of the entries whose
+                # destination has degree d, cumulated over ascending d
+                hdeg = np.diff(csr.row_ptr).astype(np.int64)
+                indeg = hdeg if not csr.directed else np.bincount(csr.col, minlength=N).astype(np.int64)
+                per_deg = np.bincount(hdeg, weights=(hdeg * indeg).astype(np.float64), minlength=self.max_degree + 1)
+                cum = np.cumsum(per_deg)
+                fit = np.nonzero(cum * FAT_BYTES <= int(budget_bytes))[0]
+                self.stored_degree_cut = int(fit[-1]) if len(fit) else 0
+                total = int(cum[self.stored_degree_cut])
+                self.partial, fat, builder = True, True, "wave"
             self.total_slots = total
             free, _ = torch.cuda.mem_get_info(d)
             if fat == "auto":
@@ -108,17 +126,26 @@ class WalkEngine:
                 N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(self.node_slots),
                 _lib.ptr(status), self._stream()))
             tick("node_tables")
+            rec_off = None
             if self.first_order:
                 self.edge_off = None
             else:
                 kdst = self.deg[self.col.long()]
+                if self.partial:
+                    stored = kdst <= self.stored_degree_cut
+                    kdst = kdst * stored
+                    stored_entries = torch.nonzero(stored).flatten().to(torch.int32).contiguous()
                 self.edge_off = torch.zeros(nnz + 1, dtype=torch.int64, device=d)
                 torch.cumsum(kdst, 0, out=self.edge_off[1:])
                 assert int(self.edge_off[-1].item()) == total, "host and device slot counts differ"
+                rec_off = self.edge_off
+                if self.partial:      # a negative offset marks an entry without a stored table (N2V_NO_TABLE)
+                    rec_off = torch.where(stored, self.edge_off[:-1], torch.full_like(self.edge_off[:-1], -1)).contiguous()
+                    self.stored_mask = stored
             # walk records first: they depend on the table OFFSETS only, and the fat slots embed them
             self.recs = torch.empty((max(nnz, 1), 4), dtype=torch.int32, device=d)
             _lib.check(self.lib.n2v_build_edge_recs(
-                N, nnz, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.edge_off), 0,
+                N, nnz, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(rec_off), 0,
                 self.max_degree, total, _lib.ptr(self.recs), self._stream()))
             tick("offsets_recs")
             if self.first_order:
@@ -133,7 +160,9 @@ class WalkEngine:
                     order = torch.argsort(kdst, descending=True).to(torch.int32)
                 work = torch.zeros(2, dtype=torch.int64, device=d)
                 # per-wave stacks of the tables that do not fit the wave's LDS slots (C3: 0.8 GB for max degree 16 614)
-                sbytes = int(self.lib.n2v_edge_tables_wave_scratch_bytes(self.max_degree)) if builder == "wave" else 0
+                built_max = self.stored_degree_cut if self.partial else self.max_degree
+                n_build = int(stored_entries.numel()) if self.partial else nnz
+                sbytes = int(self.lib.n2v_edge_tables_wave_scratch_bytes(built_max)) if builder == "wave" else 0
                 scratch = torch.empty(max(sbytes, 64) // 8, dtype=torch.int64, device=d)
                 tick("src_of")
                 if want_thin:
@@ -145,8 +174,8 @@ class WalkEngine:
                     else:
                         _lib.check(self.lib.n2v_build_edge_tables_wave(
                             N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
-                            self.p, self.q, sym, _lib.ptr(self.edge_off), None, 0, nnz, None,
-                            _lib.ptr(self.edge_slots), None, _lib.ptr(status), work[0:].data_ptr(), self.max_degree,
+                            self.p, self.q, sym, _lib.ptr(self.edge_off), _lib.ptr(stored_entries), 0, n_build, None,
+                            _lib.ptr(self.edge_slots), None, _lib.ptr(status), work[0:].data_ptr(), built_max,
                             _lib.ptr(scratch), sbytes, self._stream()))
                     tick("edge_tables_thin")
                 if want_fat:
@@ -158,9 +187,9 @@ class WalkEngine:
                     else:
                         _lib.check(self.lib.n2v_build_edge_tables_wave(
                             N, _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), _lib.ptr(src_of),
-                            self.p, self.q, sym, _lib.ptr(self.edge_off), None, 0, nnz, _lib.ptr(self.recs),
-                            None, _lib.ptr(self.edge_fat), _lib.ptr(status), work[1:].data_ptr(), self.max_degree,
-                            _lib.ptr(scratch), sbytes, self._stream()))
+                            self.p, self.q, sym, _lib.ptr(self.edge_off), _lib.ptr(stored_entries), 0, n_build,
+                            _lib.ptr(self.recs), None, _lib.ptr(self.edge_fat), _lib.ptr(status), work[1:].data_ptr(),
+                            built_max, _lib.ptr(scratch), sbytes, self._stream()))
                     tick("edge_tables_fat")
                 del order, src_of, kdst, scratch
             if want_fat and nnz > 0:
@@ -240,6 +269,8 @@ class WalkEngine:
     def edge_table(self, e):
         if self.first_order:
             return self.node_table(int(self.csr.col[e]))
+        if self.partial and not bool(self.stored_mask[e].item()):
+            return self.build_one_edge_table(e)         # not stored under the memory budget: built on demand
         off = self.edge_off[e:e + 2].cpu().tolist()
         J, q = self.thin_view(torch.arange(off[0], off[1], device=self.device), table_node=int(self.csr.col[e]))
         return (J.cpu().numpy().astype(np.int64), q.cpu().numpy())
@@ -325,6 +356,12 @@ class WalkEngine:
         that many uniforms (include/n2v_hip.h, n2v_walk_fat); expanded here for the thin-table kernel."""
         if not self.ready:
             raise RuntimeError("preprocess() first")
+        if self.partial:          # stored tables for part of the entries: the hybrid kernel rebuilds the others per step
+            if rng == "uniforms_tiled":
+                raise ValueError("the tiled uniform layout is read by the fat-table walk kernel only")
+            return self.walk_on_the_fly(starts, num_rounds, walk_length, rng=rng, seed=seed, uniforms=uniforms,
+                                        walk_uoff=walk_uoff, pos_begin=pos_begin, pos_count=pos_count,
+                                        round_begin=round_begin, out=out, uoff_round_stride=uoff_round_stride, hybrid=True)
         d = self.device
         L = int(walk_length)
         if L < 1:
@@ -365,9 +402,10 @@ class WalkEngine:
         return walks, lens
 
     def walk_on_the_fly(self, starts, num_rounds, walk_length, rng="philox", seed=0, uniforms=None, walk_uoff=None,
-                         pos_begin=0, pos_count=None, round_begin=0, out=None, uoff_round_stride=0):
+                         pos_begin=0, pos_count=None, round_begin=0, out=None, uoff_round_stride=0, hybrid=False):
         """Launch the on-the-fly walk kernel (no stored edge tables; src/node2vec.py:97-111).
-        Same arguments and results as WalkEngine.walk."""
+        Same arguments and results as WalkEngine.walk.  hybrid: n2v_walk_hybrid — steps through entries whose table is
+        stored (preprocess(budget_bytes=...)) read it, the others rebuild theirs."""
         d = self.device
         L = int(walk_length)
         if L < 1:
@@ -389,7 +427,7 @@ class WalkEngine:
                 # one scratch row per resident wavefront; grown when a later call launches more waves than the
                 # call that first allocated it (a single node2vec_walk_on_the_fly must not pin later launches
                 # to one workgroup)
-                n_waves = min(256 * 5 * 4, max(4, (n_local + 3) // 4 * 4))
+                n_waves = min(256 * 4 * 4, max(4, (n_local + 3) // 4 * 4))
                 if scratch is None or scratch.shape[0] < n_waves * self.max_degree:
                     scratch = self._otf_scratch = torch.empty((n_waves * self.max_degree, 2), dtype=torch.int64,
                                                               device=d)
@@ -397,13 +435,17 @@ class WalkEngine:
             mode = _lib.RNG_UNIFORMS if rng == "uniforms" else _lib.RNG_PHILOX
             if uoff_round_stride and walk_uoff is not None:
                 walk_uoff = expand_round_offsets(walk_uoff, num_rounds, uoff_round_stride)
-            _lib.check(self.lib.n2v_walk_on_the_fly(
-                _lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), self.p, self.q,
-                0 if self.csr.directed else 1, self.max_degree,
-                _lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin, num_rounds, L, mode,
-                _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1), _lib.ptr(scratch),
-                0 if scratch is None else int(scratch.shape[0]), _lib.ptr(walks), _lib.ptr(lens), _lib.ptr(status),
-                self._stream()))
+            tail = (_lib.ptr(starts), n_starts, pos_begin, pos_count, round_begin, num_rounds, L, mode,
+                    _lib.ptr(uniforms), _lib.ptr(walk_uoff), int(seed) & (2**64 - 1), _lib.ptr(scratch),
+                    0 if scratch is None else int(scratch.shape[0]), _lib.ptr(walks), _lib.ptr(lens), _lib.ptr(status),
+                    self._stream())
+            head = (_lib.ptr(self.row_ptr), _lib.ptr(self.col), _lib.ptr(self.w), self.p, self.q,
+                    0 if self.csr.directed else 1, self.max_degree)
+            if hybrid:
+                _lib.check(self.lib.n2v_walk_hybrid(*head, _lib.ptr(self.node_fat), _lib.ptr(self.edge_fat),
+                                                    _lib.ptr(self.recs), *tail))
+            else:
+                _lib.check(self.lib.n2v_walk_on_the_fly(*head, *tail))
             if int(status.item()) & _lib.N2V_STATUS_ZERO_NORM:
                 raise ZeroDivisionError("float division by zero")
         return walks, lens

@@ -223,7 +223,10 @@ class Graph():
             raise NotImplementedError("popwalk=%r: only the 'none' walk is on the MI355X hot path" % (self.popwalk,))
 
     # src/node2vec.py:176-204
-    def preprocess_transition_probs(self):
+    def preprocess_transition_probs(self, budget_bytes=None):
+        """budget_bytes (extension; also the attribute `table_budget_bytes`): keep the edge tables under that many
+        bytes — tables that do not fit are rebuilt per step by the walk, as the reference's on-the-fly variant does
+        for ALL of them (src/node2vec.py:34-53); the walks are the same."""
         self._check_popwalk()
         if self.p == 0 or self.q == 0:
             raise ZeroDivisionError("float division by zero")
@@ -235,7 +238,9 @@ class Graph():
         if eng is None or eng.csr is not self._csr or eng.p != float(self.p) or eng.q != float(self.q):
             self._engine = eng = None
             eng = WalkEngine(self._csr, self.p, self.q, device=self.device)
-        eng.preprocess()
+        if budget_bytes is None:
+            budget_bytes = getattr(self, "table_budget_bytes", None)
+        eng.preprocess(budget_bytes=budget_bytes)
         self._engine = eng
         self.alias_nodes = _AliasNodes(self)
         self.alias_edges = _AliasEdges(self)
@@ -413,7 +418,7 @@ class Graph():
         callers check the last)."""
         eng = self._engine
         return bool(L > 1 and not getattr(self, "host_rng", False) and not getattr(self, "linear_uniforms", False)
-                    and getattr(self, "_walk", None) == eng.walk and eng.edge_fat is not None)
+                    and getattr(self, "_walk", None) == eng.walk and eng.edge_fat is not None and not eng.partial)
 
     def _resolve_stream_offsets(self, starts, n, num_walks, L, active):
         """Directed graph with reachable sinks: a walk that ends early consumes fewer uniforms, so the position

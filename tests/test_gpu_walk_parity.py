@@ -312,6 +312,99 @@ def test_on_the_fly_kernel_equals_table_walk_with_hubs(n2v, weighted, directed, 
     assert torch.equal(c.walks, d.walks) and torch.equal(c.lens, d.lens)
 
 
+@pytest.mark.parametrize("name", ["hub520_directed", "karate_p025_q4", "er600_p05_q2", "er600_directed", "weighted_toy"])
+def test_tables_under_a_memory_budget_walk_like_the_reference(n2v, name):
+    """preprocess_transition_probs(budget_bytes=...) with a third of the full tables' size: the tables of entries whose
+    destination has the larger degrees are not stored and the walk rebuilds them per step (n2v_walk_hybrid) — the
+    reference's walks, the reference's stream position, the reference's tables in the dict views (built on demand
+    where they are not stored)."""
+    z = load_case(name)
+    g = n2v.Graph(_nx_graph(z), bool(z["directed"]), float(z["p"]), float(z["q"]))
+    g.preprocess_transition_probs()
+    full_bytes = g._engine.total_slots * 32
+    if g._engine.first_order:
+        pytest.skip("p = q = 1: no edge tables to budget")
+    g.preprocess_transition_probs(budget_bytes=full_bytes // 3)
+    eng = g._engine
+    assert eng.partial and 0 < eng.total_slots * 32 <= full_bytes // 3 and eng.stored_degree_cut < eng.max_degree
+    n_unstored = int((~eng.stored_mask).sum())
+    assert 0 < n_unstored < eng.csr.nnz
+    for i, (seed, r, L, ndraws, has_sub, fly) in enumerate(z["walk_meta"].tolist()):
+        if fly:
+            continue
+        sub = z["walks_%d_subset" % i].tolist() if has_sub else None
+        np.random.seed(seed)
+        walks = g.simulate_walks(r, L, nodes=sub)
+        assert walks == golden_walks(z, i), (name, i)
+        chk = np.random.RandomState(seed)
+        chk.random_sample(ndraws)
+        assert np.random.random_sample() == chk.random_sample(), (name, i, "global stream position")
+    # dict views: a stored and an unstored table, both equal to the reference's
+    keys = [tuple(k) for k in z["ae_keys"].tolist()]
+    ptr = z["ae_ptr"]
+    mask = eng.stored_mask.cpu().numpy()
+    seen = set()
+    for idx, (u, v) in enumerate(keys):
+        e = eng.edge_index(int(eng.csr.dense_of([u])[0]), int(eng.csr.dense_of([v])[0]))
+        kind = bool(mask[e])
+        if kind in seen:
+            continue
+        seen.add(kind)
+        J, q = g.alias_edges[(u, v)]
+        assert np.array_equal(J, z["ae_J"][ptr[idx]:ptr[idx + 1]]), (u, v, kind)
+        assert np.array_equal(_bits(q), _bits(z["ae_q"][ptr[idx]:ptr[idx + 1]])), (u, v, kind)
+        if len(seen) == 2:
+            break
+    assert len(seen) == 2
+
+
+def test_tables_under_a_memory_budget_equal_the_c_oracle_with_hubs(n2v):
+    """20k nodes plus hubs of degree 700 and 3000, sum of deg^2 = 3x the budget: the stored tables are the low-degree
+    destinations' only, the hubs' tables (in LDS up to 512 slots, beyond that in the scratch rows) are rebuilt per
+    step — every walk equals the C oracle's (Philox and numpy streams) and the full-table engine's."""
+    import torch
+    from oracle import c_oracle
+    rs = np.random.RandomState(11)
+    n, m = 20000, 80000
+    src = rs.randint(0, n, size=m)
+    dst = rs.randint(0, n, size=m)
+    hub_s = np.concatenate([np.full(700, 5), np.full(3000, 17)])
+    hub_d = np.concatenate([rs.choice(n, 700, replace=False), rs.choice(n, 3000, replace=False)])
+    src, dst = np.concatenate([src, hub_s]), np.concatenate([dst, hub_d])
+    keep = src != dst
+    from n2v_hip import csr
+    cg = csr.from_edges(src[keep], dst[keep], None, False)
+    p, q = 0.25, 4.0
+    g = n2v.Graph.from_csr(cg, p, q, rng="philox", seed=31)
+    g.preprocess_transition_probs()
+    full = g._engine.total_slots * 32
+    ref = g.simulate_walks(2, 40)
+    ref_w, ref_l = ref.walks.clone(), ref.lens.clone()
+    g.preprocess_transition_probs(budget_bytes=full // 3)
+    eng = g._engine
+    assert eng.partial and eng.total_slots * 32 <= full // 3 and eng.stored_degree_cut < eng.max_degree
+    assert int((~eng.stored_mask).sum()) > 0
+    got = g.simulate_walks(2, 40)
+    assert torch.equal(got.walks, ref_w) and torch.equal(got.lens, ref_l)
+    co = c_oracle.CsrOracle(cg.row_ptr, cg.col, cg.w, p, q)
+    co.preprocess()
+    ow, ol, _ = co.walk(cg.start_order, 2, 40, mode="philox", seed=31)
+    assert np.array_equal(got.walks.cpu().numpy(), ow) and np.array_equal(got.lens.cpu().numpy(), ol)
+    g.rng = "numpy"
+    np.random.seed(9)
+    got = g.simulate_walks(1, 25)
+    ow, ol, _ = co.walk(cg.start_order, 1, 25, mode="mt", seed=9)
+    assert np.array_equal(got.walks.cpu().numpy(), ow)
+    # a budget that holds everything changes nothing; one that holds nothing leaves only the node tables
+    g.preprocess_transition_probs(budget_bytes=full)
+    assert not g._engine.partial
+    g.rng = "philox"
+    g.preprocess_transition_probs(budget_bytes=0)
+    assert g._engine.partial and g._engine.total_slots == 0
+    got = g.simulate_walks(2, 40)
+    assert torch.equal(got.walks, ref_w)
+
+
 def test_on_the_fly_zero_weight_raises(n2v):
     import networkx as nx
     G = nx.Graph()
