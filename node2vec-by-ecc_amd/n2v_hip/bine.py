@@ -366,18 +366,24 @@ class BineEngine:
                 merge(self)
             if self.finish_iteration(epsilon)[1]:
                 break
+        if merge is not None and hasattr(merge, "flush"):
+            merge.flush(self)          # an overlapped merge still owes the last pass's foreign changes
         self.lam = float(self.state[0].item())
         return self.losses
 
-    def train_sharded(self, comm, rank, world, **kw):
+    def train_sharded(self, comm, rank, world, overlap=False, **kw):
         """One process per GPU (BASELINE config 5 on 8 GPUs): every rank holds the whole graph, walks, pools and
         a replica of both tables (all derived from the same seeds, so identical without communication), passes
         over its contiguous range of the rating list, and the replicas' changes are summed over RCCL before the
-        learning-rate step — every rank then holds what one shared table would have received."""
+        learning-rate step — every rank then holds what one shared table would have received.  overlap=True: the
+        2 GB all-reduce of a pass's changes runs UNDER the next pass (OverlappedReplicaMerge: the other ranks' changes
+        arrive one pass late; sums commute, so nothing is lost or applied twice — but a pass then reads rows that lack
+        the others' previous pass, so this is an opt-in whose loss curve has to be compared, not a bit-equal variant)."""
         per = -(-self.g.n_ratings // world)
         e0 = min(rank * per, self.g.n_ratings)
         self._prepare(kw.get("mode", "parallel"))
-        return self.train(e_range=(e0, min(e0 + per, self.g.n_ratings)), merge=ReplicaMerge(self, comm), **kw)
+        merge = OverlappedReplicaMerge(self, comm) if overlap else ReplicaMerge(self, comm)
+        return self.train(e_range=(e0, min(e0 + per, self.g.n_ratings)), merge=merge, **kw)
 
     # ------------------------------------------------------------------ results
     def vectors(self, side, which="embedding"):
@@ -411,3 +417,50 @@ class ReplicaMerge:
         part = engine.state[1:2].clone()
         self.comm.all_reduce_sum(part)
         engine.state[1:2].copy_(part)
+
+
+class OverlappedReplicaMerge:
+    """ReplicaMerge with the big all-reduce off the critical path (BASELINE config 5 at 8 GPUs: 2 x 10^6 x 256 changes
+    = 2.05 GB as fp32 per pass, against a 12 ms pass).  At the end of pass i a rank
+      1. takes its own change of the pass, d_i = x - xs (xs = the table when the pass began),
+      2. adds what the OTHER ranks changed in pass i-1 (S_{i-1} - d_{i-1}, whose all-reduce ran under pass i),
+      3. starts the all-reduce of d_i (async_op: it runs on the communicator's stream under pass i+1).
+    Every change is applied exactly once on every rank (its owner applies it while training, the others one pass
+    later), so after flush() all ranks hold start + the sum of all changes — the same total as the synchronous merge,
+    bit for bit when the sums are exact (tests/test_bine_host.py).  Only the small loss scalar is reduced synchronously:
+    the learning-rate rule (src/bine_train.py:495-502) needs the whole list's loss of THIS pass."""
+
+    def __init__(self, engine, comm):
+        self.comm = comm
+        self.xs = [engine.emb.clone(), engine.ctx.clone()]
+        self.pending = None          # [(summed-change buffer, own change, handle)] of the previous pass
+
+    def _fold_pending(self, tables):
+        if self.pending is None:
+            return
+        for t, (buf, own, handle) in zip(tables, self.pending):
+            if handle is not None:
+                handle.wait()
+            buf.sub_(own)            # what the other ranks changed
+            t.add_(buf.to(t.dtype))
+        self.pending = None
+
+    def __call__(self, engine):
+        wire = getattr(self.comm, "wire_dtype_f64", None)
+        tables = (engine.emb, engine.ctx)
+        own = [(t - xs).to(wire if wire is not None else t.dtype) for t, xs in zip(tables, self.xs)]
+        self._fold_pending(tables)
+        nxt = []
+        for t, xs, d in zip(tables, self.xs, own):
+            xs.copy_(t)
+            buf = d.clone()
+            nxt.append((buf, d, self.comm.all_reduce_async(buf)))
+        self.pending = nxt
+        part = engine.state[1:2].clone()
+        self.comm.all_reduce_sum(part)
+        engine.state[1:2].copy_(part)
+
+    def flush(self, engine):
+        self._fold_pending((engine.emb, engine.ctx))
+        for t, xs in zip((engine.emb, engine.ctx), self.xs):
+            xs.copy_(t)

@@ -179,6 +179,30 @@ for step in range(2):
     assert torch.equal(eng.ctx, wc)
     assert eng.state[1].item() == -7.0
     assert torch.equal(merge.base[0], eng.emb) and torch.equal(merge.base[1], eng.ctx)
+# the overlapped merge (all-reduce of pass i under pass i+1): same totals as the synchronous one, bit for bit, for
+# changes that do not depend on what the other rank did (integer-valued here, so every sum is exact); between the
+# passes a rank sees the other's changes ONE PASS LATE, and flush() settles the last one
+eng_s = types.SimpleNamespace(emb=base.clone(), ctx=-base.clone(), state=torch.zeros(8, dtype=torch.float64))
+eng_o = types.SimpleNamespace(emb=base.clone(), ctx=-base.clone(), state=torch.zeros(8, dtype=torch.float64))
+sync, over = bine.ReplicaMerge(eng_s, comm), bine.OverlappedReplicaMerge(eng_o, comm)
+for step in range(3):
+    for eng in (eng_s, eng_o):
+        eng.emb[rank] += 1.0 + rank + step
+        eng.emb[3] += 10.0 * (rank + 1)
+        eng.ctx[2] -= 4.0 + step
+        eng.state[1] = -(3.0 + rank + step)
+    sync(eng_s)
+    over(eng_o)
+    assert eng_o.state[1].item() == eng_s.state[1].item() == -(7.0 + 2 * step)      # the loss is never late
+    other = 1 - rank
+    late = eng_s.emb.clone()
+    late[other] -= 1.0 + other + step                  # the other rank's change of THIS pass has not arrived yet
+    late[3] -= 10.0 * (other + 1)
+    assert torch.equal(eng_o.emb, late), (step, eng_o.emb, late)
+over.flush(eng_o)
+assert torch.equal(eng_o.emb, eng_s.emb) and torch.equal(eng_o.ctx, eng_s.ctx)
+assert torch.equal(over.xs[0], eng_o.emb) and over.pending is None
+chk = eng_o.emb.clone(); dist.broadcast(chk, src=0); assert torch.equal(chk, eng_o.emb)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

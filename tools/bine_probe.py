@@ -30,6 +30,8 @@ def parser():
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--mode", default="parallel", choices=["parallel", "atomic", "store"])
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
+    ap.add_argument("--overlap-merge", action="store_true",
+                    help="N > 1: the all-reduce of a pass's changes runs under the next pass (OverlappedReplicaMerge)")
     ap.add_argument("--split", action="store_true", help="also time a pass with the skip-gram blocks disabled (KL only)")
     return ap
 
@@ -71,7 +73,7 @@ def run(args, ctx=None, emit=True):
 
     def run(**kw):
         if ctx.world > 1:
-            return e.train_sharded(ctx.comm, ctx.rank, ctx.world, **kw)
+            return e.train_sharded(ctx.comm, ctx.rank, ctx.world, overlap=getattr(args, "overlap_merge", False), **kw)
         return e.train(**kw)
 
     timed("hits", e.calculate_centrality)
