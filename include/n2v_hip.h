@@ -210,6 +210,9 @@ int n2v_mt19937_fill_tiled(const uint32_t* states, int32_t n_streams, int32_t po
  * floor(scratch_slots / max_degree) wavefronts, at least 4 are required when
  * max_degree > 512; may be NULL otherwise).  status: int32[1], N2V_STATUS_ZERO_NORM on a
  * zero-sum neighbourhood.  Other arguments as n2v_walk.                                   */
+/* Largest table the on-the-fly / hybrid kernels build in LDS, and the most wavefronts a launch uses (= scratch rows). */
+int32_t n2v_walk_otf_lds_slots(void);
+int32_t n2v_walk_otf_max_waves(void);
 int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
                         int32_t symmetric, int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
                         int64_t pos_count, int64_t round_begin, int64_t round_count,

@@ -13,7 +13,7 @@
 //   2. runs the two inherently serial pieces in the reference's order — the left-to-right fp64 sum (:149) and
 //      Vose's stack pairing (:259-268) — fed from registers (n2v_wave_table.h, shared with the table builder),
 //   3. normalises (divide, then multiply by K) in parallel again, and draws.
-// The table lives in the wave's slice of LDS while K <= kLdsSlots and in a per-wave global
+// The table lives in the wave's slice of LDS while K <= kLdsSlots (256) and in a per-wave global
 // scratch row of max_degree slots otherwise.  Serial chains of many waves interleave on a
 // SIMD, so throughput comes from occupancy; -ffp-contract=off keeps every rounding separate.
 #include "n2v_common.h"
@@ -21,7 +21,12 @@
 
 namespace {
 
-constexpr int kLdsSlots = 512;  // 8 KiB of LDS per wave, 32 KiB per 4-wave workgroup
+#ifndef N2V_OTF_LDS_SLOTS
+#define N2V_OTF_LDS_SLOTS 256   /* 6 KiB per wave -> 6 workgroups per CU: C3 2.1 -> 2.6e8 steps/s vs 512 slots / 4 workgroups; 128: 2.5e8 */
+#endif
+constexpr int kLdsSlots = N2V_OTF_LDS_SLOTS;  // 16 B per slot and wave, plus the feed and row cache of n2v_wave_table.h
+constexpr int kLdsPerWg = 4 * (kLdsSlots * 16 + n2v::kFeed * 8 + n2v::kRowCache * 4);
+constexpr int kWgPerCu = (160 * 1024 / kLdsPerWg) < 8 ? (160 * 1024 / kLdsPerWg) : 8;
 
 using n2v::uni;
 using n2v::uni64;
@@ -163,7 +168,7 @@ int launch_otf(const char* who, bool hybrid, const int64_t* row_ptr, const int32
         return n2v::fail(N2V_ERR_INVALID, "%s: parity mode needs a uniform buffer", who);
     // grid: as many resident waves as the scratch rows allow (4 workgroups of 4 waves per CU by LDS)
     int64_t blocks = (n_local + 3) / 4;
-    if (blocks > 256 * 4) blocks = 256 * 4;   // 40 KiB of LDS per workgroup: 4 per CU
+    if (blocks > 256 * kWgPerCu) blocks = 256 * kWgPerCu;   // every resident workgroup slot (LDS-bound), once
     if (max_degree > kLdsSlots) {
         if (!scratch) return n2v::fail(N2V_ERR_INVALID, "%s: scratch needed (max degree %lld > %d)", who,
                                        (long long)max_degree, kLdsSlots);
@@ -178,6 +183,9 @@ int launch_otf(const char* who, bool hybrid, const int64_t* row_ptr, const int32
     return n2v::check_launch(who);
 }
 }  // namespace
+
+extern "C" int32_t n2v_walk_otf_lds_slots(void) { return kLdsSlots; }
+extern "C" int32_t n2v_walk_otf_max_waves(void) { return 256 * kWgPerCu * 4; }
 
 extern "C" int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q,
                                    int32_t symmetric, int64_t max_degree, const int32_t* starts, int64_t n_starts, int64_t pos_begin,

@@ -47,6 +47,8 @@ SIGNATURES = {
                                _ptr, _ptr, _ptr]),
     "n2v_walk_on_the_fly": (C.c_int, [_ptr, _ptr, _ptr, _f64, _f64, _i32, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i32,
                                       _i32, _ptr, _ptr, _u64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
+    "n2v_walk_otf_lds_slots": (C.c_int32, []),
+    "n2v_walk_otf_max_waves": (C.c_int32, []),
     "n2v_walk_hybrid": (C.c_int, [_ptr, _ptr, _ptr, _f64, _f64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64,
                                   _i64, _i32, _i32, _ptr, _ptr, _u64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "n2v_sgns_init": (C.c_int, [_ptr, _ptr, _i64, _i32, _i32, _u64, _ptr]),

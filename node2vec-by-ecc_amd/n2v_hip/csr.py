@@ -184,3 +184,19 @@ def read_edgelist(path, weighted=False, directed=False):
             if weighted:
                 w.append(float(tok[2]))
     return from_edges(src, dst, w if weighted else None, directed)
+
+
+def degree_cut_for_budget(csr, budget_bytes, bytes_per_slot=32):
+    """Tables under a memory budget (WalkEngine.preprocess(budget_bytes=...)): the largest degree D such that the
+    edge tables of all entries (src -> dst) with deg(dst) <= D fit in `budget_bytes`, and the number of slots they
+    take.  A table (src -> dst) has deg(dst) slots and there is one per in-edge of dst, so destinations of degree d
+    cost sum over them of deg * indeg slots.  Host arithmetic only."""
+    hdeg = np.diff(csr.row_ptr).astype(np.int64)
+    indeg = hdeg if not csr.directed else np.bincount(csr.col, minlength=csr.n_nodes).astype(np.int64)
+    max_degree = int(hdeg.max()) if csr.n_nodes else 0
+    per_deg = np.zeros(max_degree + 1, dtype=np.int64)
+    np.add.at(per_deg, hdeg, hdeg * indeg)
+    cum = np.cumsum(per_deg)
+    fit = np.nonzero(cum * int(bytes_per_slot) <= int(budget_bytes))[0]
+    cut = int(fit[-1]) if len(fit) else 0
+    return cut, int(cum[cut])

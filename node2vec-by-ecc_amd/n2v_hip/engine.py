@@ -84,15 +84,9 @@ class WalkEngine:
             total = nnz if self.first_order else self.total_edge_slots
             self.partial, self.stored_degree_cut, stored_entries = False, None, None
             if budget_bytes is not None and not self.first_order and total * FAT_BYTES > int(budget_bytes):
-                # host arithmetic (no device reduction before the big allocation): slots of the entries whose
-                # destination has degree d, cumulated over ascending d
-                hdeg = np.diff(csr.row_ptr).astype(np.int64)
-                indeg = hdeg if not csr.directed else np.bincount(csr.col, minlength=N).astype(np.int64)
-                per_deg = np.bincount(hdeg, weights=(hdeg * indeg).astype(np.float64), minlength=self.max_degree + 1)
-                cum = np.cumsum(per_deg)
-                fit = np.nonzero(cum * FAT_BYTES <= int(budget_bytes))[0]
-                self.stored_degree_cut = int(fit[-1]) if len(fit) else 0
-                total = int(cum[self.stored_degree_cut])
+                # host arithmetic (no device reduction before the big allocation)
+                from .csr import degree_cut_for_budget
+                self.stored_degree_cut, total = degree_cut_for_budget(csr, budget_bytes, FAT_BYTES)
                 self.partial, fat, builder = True, True, "wave"
             self.total_slots = total
             free, _ = torch.cuda.mem_get_info(d)
@@ -423,11 +417,11 @@ class WalkEngine:
             else:
                 walks, lens = out
             scratch = getattr(self, "_otf_scratch", None)
-            if self.max_degree > 512:
+            if self.max_degree > int(self.lib.n2v_walk_otf_lds_slots()):
                 # one scratch row per resident wavefront; grown when a later call launches more waves than the
                 # call that first allocated it (a single node2vec_walk_on_the_fly must not pin later launches
                 # to one workgroup)
-                n_waves = min(256 * 4 * 4, max(4, (n_local + 3) // 4 * 4))
+                n_waves = min(int(self.lib.n2v_walk_otf_max_waves()), max(4, (n_local + 3) // 4 * 4))
                 if scratch is None or scratch.shape[0] < n_waves * self.max_degree:
                     scratch = self._otf_scratch = torch.empty((n_waves * self.max_degree, 2), dtype=torch.int64,
                                                               device=d)

@@ -191,3 +191,47 @@ def test_save_embeddings_creates_the_output_directory(tmp_path):
     target = tmp_path / "emb" / "deep" / "karate.emb"
     n2v_main.save_embeddings(Emb, str(target))
     assert target.read_text() == "0 0\n"
+
+
+def test_tiled_uniform_layout_is_a_bijection_and_groups_steps():
+    """n2v_hip.mt19937.tiled_index (the documented mapping of n2v_mt19937_fill_tiled / N2V_RNG_UNIFORMS_TILED): every
+    stream double has its own place inside tiled_size(n), and the pairs of ONE step of 64 consecutive walk segments are
+    1 KiB of consecutive doubles."""
+    from n2v_hip import mt19937
+    for n_walks, pairs in ((64, 79), (1000, 79), (130, 1), (65, 24), (5, 3)):
+        n = n_walks * 2 * pairs
+        idx = mt19937.tiled_index(np.arange(n), pairs)
+        size = mt19937.tiled_size(n, pairs)
+        assert size == -(-n_walks // 64) * 64 * 2 * pairs
+        assert idx.min() >= 0 and idx.max() < size and len(np.unique(idx)) == n
+        for s0 in range(0, n_walks - n_walks % 64, 64):          # whole groups of 64 segments
+            for t in (0, pairs - 1):
+                d = (np.arange(s0, s0 + 64) * 2 * pairs + 2 * t)[:, None] + np.arange(2)[None, :]
+                got = mt19937.tiled_index(d.reshape(-1), pairs)
+                assert np.array_equal(got, got[0] + np.arange(128))
+    assert mt19937.auto_streams(10**6) == mt19937.N_STREAMS and mt19937.auto_streams(1.6e9) > 2 * mt19937.N_STREAMS
+    assert mt19937.auto_streams(10**12) == 4 * mt19937.N_STREAMS
+
+
+def test_degree_cut_for_a_table_budget():
+    """csr.degree_cut_for_budget: the stored tables are those of the destinations up to a degree cut, their slots
+    counted as sum of deg(dst) over the entries — undirected and directed."""
+    from n2v_hip import csr
+    rs = np.random.RandomState(3)
+    src, dst = rs.randint(0, 300, 3000), rs.randint(0, 300, 3000)
+    keep = src != dst
+    hub = np.arange(1, 250)
+    for directed in (False, True):
+        g = csr.from_edges(np.concatenate([src[keep], np.zeros_like(hub)]), np.concatenate([dst[keep], hub]), None, directed)
+        deg = np.diff(g.row_ptr)
+        k_entry = deg[g.col]                                   # slots of the table of each CSR entry
+        full = int(k_entry.sum())
+        assert csr.degree_cut_for_budget(g, full * 32) == (int(deg.max()), full)
+        assert csr.degree_cut_for_budget(g, -1)[1] == 0
+        for frac in (0.1, 0.33, 0.5, 0.9):
+            cut, slots = csr.degree_cut_for_budget(g, int(full * 32 * frac))
+            assert slots == int(k_entry[k_entry <= cut].sum()) and slots * 32 <= full * 32 * frac
+            nxt = k_entry[k_entry > cut]
+            if len(nxt):                                        # the next degree would not fit
+                d2 = int(nxt.min())
+                assert int(k_entry[k_entry <= d2].sum()) * 32 > full * 32 * frac
