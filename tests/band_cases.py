@@ -72,6 +72,8 @@ CASES = {
     "hub20k_10x80": ("hub", {}, 10, 80),
     "hub131k_10x80": ("hub", dict(n=131072, k=131072 // 200, m_in=10 * 131072, m_out=2 * 131072, seed=2), 10, 80),
     "hub131k_5x40": ("hub", dict(n=131072, k=131072 // 200, m_in=10 * 131072, m_out=2 * 131072, seed=2), 5, 40),
+    # above the `auto` switch to agent-scope rows (>= 131 072 rows, >= 600 tokens per row); comparator: ~4 h of one core
+    "hub400k_10x80": ("hub", dict(n=400000, k=2000, m_in=4000000, m_out=800000, seed=3), 10, 80),
 }
 
 

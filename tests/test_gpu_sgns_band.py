@@ -43,13 +43,17 @@ def gpu_case(name):
     return out
 
 
+_HAVE_400K = __import__("os").path.exists(band_cases.fixture_path("hub400k_10x80"))   # 4 h of comparator: optional fixture
+
+
 @pytest.mark.parametrize("name,mode,resolved", [
     ("uniform3k_10x80", "auto", "atomic"),
     ("hub20k_10x80", "auto", "atomic"),
     ("hub131k_10x80", "agent", "agent"),     # the mode bench.py's C3 line runs, at the size where `auto` switches to it
     ("hub131k_10x80", "atomic", "atomic"),   # (this graph has 131 019 connected nodes, 53 short of the switch: `auto` = atomic)
     ("hub131k_5x40", "auto", "atomic"),      # src/settings.py's main_link defaults: 200 tokens per row -> lossless rows
-])
+] + ([("hub400k_10x80", "auto", "agent"),    # above the `auto` switch: agent rows chosen by the rule itself
+      ("hub400k_10x80", "atomic", "atomic")] if _HAVE_400K else []))
 def test_single_gpu_auc_within_band_of_sequential_comparator(name, mode, resolved):
     import torch
     from n2v_hip import linkpred, sgns
