@@ -162,15 +162,39 @@ __device__ __forceinline__ void wave_pair(const Stacks& S, Sink& out, int K, int
                 s_pos = 0;
             }
             const int first = s_pos;
-            bool demoted = false;
-            for (;;) {
-                const double qs = readlane_f64(sq, s_pos);
-                ++s_pos;
-                ql = ql + qs;              // :264
-                ql = ql - 1.0;
-                if (ql < 1.0) { demoted = true; break; }
-                if (s_pos >= s_cnt) break;
+            // The chain of one large over the buffered smalls, hand-scheduled (hipcc's version of this loop is 15
+            // instructions per small, most of them re-deriving exit masks on the scalar unit; this is 10): VCC doubles
+            // as the 64-bit scalar operand the two v_readlane fill.  Same operations, same order, same roundings:
+            //   ql = (ql + q[s_pos]) - 1.0; ++s_pos; stop when ql < 1.0 (demoted) or the buffer is used up.
+            int dem;
+            {
+                const int sq_lo = __double2loint(sq), sq_hi = __double2hiint(sq);
+                int pos = uni(s_pos);
+                const int cnt = uni(s_cnt);
+                asm volatile(
+                    "s_nop 3\n\t"                                  // %[pos] may come from a v_readfirstlane: lane-select hazard
+                    "1:\n\t"
+                    "v_readlane_b32 vcc_lo, %[qlo], %[pos]\n\t"
+                    "v_readlane_b32 vcc_hi, %[qhi], %[pos]\n\t"
+                    "s_add_i32 %[pos], %[pos], 1\n\t"
+                    "s_nop 0\n\t"                                  // VALU-written SGPR -> VALU operand: two wait states
+                    "v_add_f64 %[ql], %[ql], vcc\n\t"
+                    "v_add_f64 %[ql], %[ql], -1.0\n\t"
+                    "v_cmp_gt_f64 vcc, 1.0, %[ql]\n\t"
+                    "s_cbranch_vccnz 2f\n\t"
+                    "s_cmp_lt_i32 %[pos], %[cnt]\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "s_mov_b32 %[dem], 0\n\t"
+                    "s_branch 3f\n\t"
+                    "2:\n\t"
+                    "s_mov_b32 %[dem], 1\n\t"
+                    "3:\n\t"
+                    : [ql] "+v"(ql), [pos] "+s"(pos), [dem] "=s"(dem)
+                    : [qlo] "v"(sq_lo), [qhi] "v"(sq_hi), [cnt] "s"(cnt)
+                    : "vcc", "scc");
+                s_pos = pos;
             }
+            const bool demoted = dem != 0;
             out.run(lane >= first && lane < s_pos, si, sq, large);         // :263 for every small of this run
             if (demoted) { carried = true; cs_i = large; cs_q = ql; break; }
         }
