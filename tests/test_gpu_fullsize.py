@@ -201,3 +201,40 @@ def test_auto_row_sharing_agrees_with_lossless_mode_at_200k(torch_cuda):
         assert m.update_mode_name == ("agent" if mode == "auto" else "atomic")
     print("AUC auto(agent) %.5f atomic %.5f" % (aucs["auto"], aucs["atomic"]))
     assert aucs["atomic"] > 0.85 and abs(aucs["auto"] - aucs["atomic"]) <= 0.002
+
+
+def test_c2_reference_exact_layouts_budget_and_stream_position(torch_cuda):
+    """C2 at full size, reference-exact mode (numpy's MT19937 stream regenerated on the device): the tiled uniform
+    layout, the linear one and a chunked call walk identically and leave numpy's global state where 2 * steps draws
+    leave it; the same walks again with a third of the edge tables stored (n2v_walk_hybrid)."""
+    torch = torch_cuda
+    import node2vec
+    from n2v_hip import synth
+    cg, _ = synth.make_config_graph("C2")
+    g = node2vec.Graph.from_csr(cg, 0.25, 4.0, rng="numpy")
+    g.preprocess_transition_probs()
+    eng = g._engine
+    full_bytes = eng.total_slots * 32
+    r, L = 2, 80
+    res = []
+    for kw in (dict(), dict(linear_uniforms=True), dict(uniform_chunk_rounds=1)):
+        for k in ("linear_uniforms", "uniform_chunk_rounds"):
+            g.__dict__.pop(k, None)
+        g.__dict__.update(kw)
+        np.random.seed(2024)
+        c = g.simulate_walks(r, L)
+        st = np.random.get_state()
+        res.append((c.walks.clone(), st[1].copy(), st[2]))
+    for k in ("linear_uniforms", "uniform_chunk_rounds"):
+        g.__dict__.pop(k, None)
+    _check_walks(torch, eng, res[0][0], torch.full((cg.n_nodes * r,), L, dtype=torch.int32, device="cuda"), eng.start_order, r)
+    for other in res[1:]:
+        assert torch.equal(other[0], res[0][0]) and np.array_equal(other[1], res[0][1]) and other[2] == res[0][2]
+    chk = np.random.RandomState(2024)
+    chk.random_sample(2 * (L - 1) * cg.n_nodes * r)
+    assert np.random.random_sample() == chk.random_sample()
+    g.preprocess_transition_probs(budget_bytes=full_bytes // 3)
+    assert g._engine.partial
+    np.random.seed(2024)
+    c = g.simulate_walks(r, L)
+    assert torch.equal(c.walks, res[0][0])

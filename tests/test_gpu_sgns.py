@@ -521,7 +521,6 @@ def test_tiered_merges_graph_replay_equals_eager_loop(torch_cuda):
         n_words, L, epochs = 1500, 24, 2
         p = rs.pareto(1.1, n_words) + 0.05
         p /= p.sum()
-        probe = sgns.SgnsModel(n_words, dim=64, seed=5)
         results = []
         walks = None
         for graph in (False, True):
