@@ -38,6 +38,12 @@ AUTO_AGENT_MIN_TOKENS_PER_WORD = 600
 # 0.0047 / 0.0064 at 4 / 8 replicas on a 131 072-node hub graph: above this vocabulary size it has to be
 # asked for with allow_out_of_band=True
 HOT_MERGE_MAX_WORDS = 1 << 15
+# walk_splits="auto" (several wavefronts per sentence, for the short launches between hub-tier merges) only on tables of
+# at least this many rows: a short launch starts all splits of a sentence at the same instant, which adds a POSITIVE AUC
+# offset that grows with the number of launches and shrinks with the table size — 20k-row hub graph, tiered merges:
+# +0.0026 / +0.0013 at 2 / 8 replicas with splits against +0.0014 / -0.0001 without; 131k rows with splits: +0.0010 /
+# +0.0001 (tests/probes/split_bias_probe.py, profiles/r03/logs/split_bias_probe_hub20k.log)
+AUTO_SPLITS_MIN_WORDS = 1 << 16
 MAX_WORDS_IN_BATCH = 10000  # gensim: words per job; alpha is stepped once per job
 
 
@@ -100,6 +106,14 @@ def resolve_update_mode(requested, n_words, n_tokens, allow_out_of_band=False):
             "on a short corpus).  Use 'auto' / 'atomic', or pass allow_out_of_band=True"
             % (requested, AUTO_AGENT_MIN_WORDS, AUTO_AGENT_MIN_TOKENS_PER_WORD, n_words, float(n_tokens) / max(n_words, 1)))
     return requested
+
+
+def auto_splits(n_words, n_walks, walk_length):
+    """Wavefronts per sentence of a launch of n_walks walks: as many as it takes to put ~8 192 wavefronts on the chip,
+    at most one per token — and none on tables below AUTO_SPLITS_MIN_WORDS rows (see there)."""
+    if n_words < AUTO_SPLITS_MIN_WORDS:
+        return 1
+    return max(1, min(int(walk_length), -(-8192 // max(int(n_walks), 1))))
 
 
 def launch_update_mode(mode_bits, auto, splits, allow_out_of_band=False):
@@ -197,7 +211,7 @@ class SgnsModel:
     def _launch(self, walks_ptr, lens_ptr, n, L, sentences_base, sentences_step, sentences_total, walk_id_base,
                 max_blocks, splits, stream):
         if splits == "auto":
-            splits = max(1, min(L, -(-8192 // n)))
+            splits = auto_splits(self.n_words, n, L)
         mode = launch_update_mode(self.update_mode, self._auto_mode, splits, self.allow_out_of_band)
         _lib.check(self.lib.n2v_sgns_train(
             walks_ptr, lens_ptr, n, L, _lib.ptr(self.syn0), _lib.ptr(self.syn1neg), self.n_words,
@@ -235,7 +249,7 @@ class SgnsModel:
         n_local, L = int(walks.shape[0]), int(walks.shape[1])
         max_walks = -(-n_local // int(n_sub_total))
         if splits == "auto":
-            splits = max(1, min(L, -(-8192 // max(max_walks, 1))))
+            splits = auto_splits(self.n_words, max_walks, L)
         mode = launch_update_mode(self.update_mode, self._auto_mode, splits, self.allow_out_of_band)
         dev = self.device
 
@@ -463,7 +477,7 @@ class _SimGroup:
 
 
 def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="auto", merge="tsum", epochs=1,
-                             cold_delay=False, wire_dtype=torch.bfloat16):
+                             cold_delay=False, wire_dtype=torch.bfloat16, splits="auto"):
     """Validation helper: `models` are G replicas on one device, `shards[r] = (walks, lens, shard_offset)` what
     rank r would hold.  Runs the schedule of `train` with one ReplicaMerger per replica — the same kernels, the
     same two tiers, the same one-interval delay of the cold rows — so the multi-GPU scheme can be scored for AUC
@@ -484,7 +498,7 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
                     if e > b:
                         m.train_pass(w[b:e], None if l is None else l[b:e], sentences_base=ep * n_walks_global + b * G,
                                      sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b,
-                                     splits="auto")
+                                     splits=splits)
                 level = plan.level_due(c)
                 if level is None:
                     continue
@@ -507,7 +521,7 @@ def train_simulated_replicas(models, shards, n_walks_global, syncs_per_epoch="au
                 if e > b:
                     m.train_pass(w[b:e], None if l is None else l[b:e], sentences_base=ep * n_walks_global + b * G,
                                  sentences_step=G, sentences_total=total, walk_id_base=ep * n_walks_global + off + b,
-                                     splits="auto")
+                                     splits=splits)
             for mg in mergers:
                 mg.snapshot()
             if mergers[0].hot_wire is not None:

@@ -427,6 +427,9 @@ def test_out_of_band_modes_are_fenced():
     with pytest.raises(sgns.OutOfBandError):
         sgns.launch_update_mode(G, False, 8)
     assert sgns.launch_update_mode(G, False, 8, allow_out_of_band=True) == G | 8   # N2V_SGNS_UNCHECKED
+    # several wavefronts per sentence only on large tables (the short launches' synchronous starts bias small graphs)
+    assert sgns.auto_splits(20000, 13, 80) == 1 and sgns.auto_splits(sgns.AUTO_SPLITS_MIN_WORDS, 13, 80) == 80
+    assert sgns.auto_splits(10**6, 83, 80) == 80 and sgns.auto_splits(10**6, 1000, 80) == 9 and sgns.auto_splits(10**6, 10**5, 80) == 1
     # merge="hot" above the size it was shown to hold at
     sgns.check_merge_in_band("tsum", 10**7)
     sgns.check_merge_in_band("hot", 20000)
