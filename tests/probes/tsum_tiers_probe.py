@@ -15,9 +15,10 @@ from n2v_hip import merge, sgns
 cases = sys.argv[1:] or ["hub131k_10x80", "hub20k_10x80", "uniform3k_10x80"]
 plan_cls = merge.SumTierPlan
 for name in cases:
-    for tiers, theta in ((4, 125.0), (3, 125.0), (3, 60.0), (2, 125.0)):
+    for tiers, theta in [tuple(float(x) for x in t.split(":")) for t in os.environ.get("TIERS", "4:125,3:125,3:60,2:125").split(",")]:
+        tiers = int(tiers)
         sgns.SumTierPlan = lambda *a, _t=tiers, _th=theta, **k: plan_cls(*a, theta=_th, n_tiers=_t, **k)
-        for G in (8, 4, 2):
+        for G in [int(x) for x in os.environ.get("GS", "8,4,2").split(",")]:
             t = time.time()
             auc, cpu, n_syncs, mode = tb._simulated_replicas(name, G, "auto")
             print("%s tiers %d theta %3.0f G=%d: AUC %.5f vs %.5f (%+.5f)  base syncs %d  %.0f s" % (
