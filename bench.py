@@ -501,8 +501,8 @@ def main():
         # N > 1 (rank 0's timers): seconds per step the compute stream spent in the merge phases, of which waiting
         # for the cold rows' all-reduce; overlap_fraction = share of that all-reduce's stand-alone cost that was
         # hidden under training
-        "merge_seconds": merge_secs["merge"] / K if world > 1 else None,
-        "merge_wait_seconds": merge_secs["wait"] / K if world > 1 else None,
+        "merge_seconds": merge_secs["merge"] / K if world > 1 and mergers else None,       # None: not timed (graph replay)
+        "merge_wait_seconds": merge_secs["wait"] / K if world > 1 and mergers else None,
         "merges_per_step": (merge_secs["n"] / K if merge_secs["n"] else graph_mode.get("merges")) if world > 1 else None,
         # tsum without --merge-timers: one base interval captured as a HIP graph and replayed this many times per pass
         "merge_graph_replays_per_step": graph_mode["replays"] if world > 1 else None,
