@@ -83,13 +83,19 @@ class WalkEngine:
             self.first_order = bool(first_order_shortcut and self.p == 1.0 and self.q == 1.0)
             total = nnz if self.first_order else self.total_edge_slots
             self.partial, self.stored_degree_cut, stored_entries = False, None, None
+            free, _ = torch.cuda.mem_get_info(d)
+            free += torch.cuda.memory_reserved(d) - torch.cuda.memory_allocated(d)    # the allocator's cache is ours to reuse
+            if (budget_bytes is None and fat == "auto" and not self.first_order
+                    and total * SLOT_BYTES > free - (1 << 30)):
+                # not even the thin tables fit: keep the tables that do and let the walk rebuild the others per step
+                # (the reference's answer is to rebuild ALL of them, src/settings.py:18) instead of giving up
+                budget_bytes = max(0, free - (8 << 30))
             if budget_bytes is not None and not self.first_order and total * FAT_BYTES > int(budget_bytes):
                 # host arithmetic (no device reduction before the big allocation)
                 from .csr import degree_cut_for_budget
                 self.stored_degree_cut, total = degree_cut_for_budget(csr, budget_bytes, FAT_BYTES)
                 self.partial, fat, builder = True, True, "wave"
             self.total_slots = total
-            free, _ = torch.cuda.mem_get_info(d)
             if fat == "auto":
                 fat = (nnz + (0 if self.first_order else total)) * FAT_BYTES < free - (8 << 30)
             want_thin = fat in (False, "both")

@@ -395,6 +395,17 @@ def test_tables_under_a_memory_budget_equal_the_c_oracle_with_hubs(n2v):
     got = g.simulate_walks(1, 25)
     ow, ol, _ = co.walk(cg.start_order, 1, 25, mode="mt", seed=9)
     assert np.array_equal(got.walks.cpu().numpy(), ow)
+    # no budget given and not even the thin tables fit (simulated: "free" memory of 1.1 GB, 1 GB of it reserve): the tables that fit are kept
+    # and the rest is rebuilt per step, instead of a MemoryError
+    real = torch.cuda.mem_get_info
+    try:
+        torch.cuda.mem_get_info = lambda *a, **k: ((1 << 30) + (100 << 20) - (torch.cuda.memory_reserved() - torch.cuda.memory_allocated()), real()[1])
+        g.rng = "philox"
+        g.preprocess_transition_probs()
+    finally:
+        torch.cuda.mem_get_info = real
+    assert g._engine.partial and g._engine.total_slots == 0      # budget = free - 8 GB < 0: node tables only
+    assert torch.equal(g.simulate_walks(2, 40).walks, ref_w)
     # a budget that holds everything changes nothing; one that holds nothing leaves only the node tables
     g.preprocess_transition_probs(budget_bytes=full)
     assert not g._engine.partial
