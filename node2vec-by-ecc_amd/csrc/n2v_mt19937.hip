@@ -17,7 +17,6 @@
 // numpy's own algorithm — lazy block twist, tempering, (a>>5, b>>6) -> double — one wavefront
 // per stream with the 624-word window in LDS, and hands back the final (key, pos) so the
 // caller can leave numpy's global state exactly where the reference would have left it.
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -568,8 +567,7 @@ static int fill_common(const char* what, const uint32_t* states, int32_t n_strea
     // ring: one group of four segments (4 * dpw doubles) plus one block of fresh doubles (312) and the straddling one
     int ring_log2 = 0;
     while ((1LL << ring_log2) < 4LL * dpw + 320) ++ring_log2;
-    const char* env = getenv("N2V_MT_TILED_DIRECT");      // A/B switch for tools/mt_probe2.py
-    if (ring_log2 <= 12 && !(env && env[0] == '1')) {     // <= 32 KiB of LDS per wavefront (L <= 473)
+    if (ring_log2 <= 12) {                                // <= 32 KiB of LDS per wavefront (L <= 473)
         hipLaunchKernelGGL(mt_fill_kernel<2>, dim3((unsigned)n_streams), dim3(64), kFillLdsHead + (sizeof(double) << ring_log2),
                            (hipStream_t)stream, states, (int)pos, words_per_stream, 2 * n_doubles, out, final_state, tm,
                            ring_log2);

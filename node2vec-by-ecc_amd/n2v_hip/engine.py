@@ -4,6 +4,8 @@ arithmetic step done by the HIP kernels behind the C-ABI (include/n2v_hip.h).
 torch is used for memory, streams and index plumbing (prefix sums, size-order sort);
 the alias arithmetic and the walk are never done in torch and there is no CPU path.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -108,8 +110,7 @@ class WalkEngine:
             # multi-GB allocation that follows such a kernel takes seconds (tools/alloc_probe.py: 58 GB in 0.000 s
             # as the first thing, 3.06 s after a torch.argsort of 2e7 keys; round 1's preprocess spent 1.5-2.4 s of
             # its 2.76 s there).  The slot count comes from host arithmetic on the CSR for the same reason.
-            import time as _time
-            t_alloc = _time.perf_counter()
+            t_alloc = time.perf_counter()
             if not self.first_order:
                 if want_thin:
                     self.edge_slots = torch.empty((max(total, 1), 2), dtype=torch.int64, device=d)
@@ -118,7 +119,7 @@ class WalkEngine:
             # host time of the table allocation (hipMalloc blocks the host when the driver has to hand out memory another
             # allocation has just released: 65-80 ms per GiB, tools/alloc_probe2.py; ~0 from the allocator's cache or
             # from memory that was never used) — reported separately from the kernels by bench.py
-            self.alloc_seconds = _time.perf_counter() - t_alloc
+            self.alloc_seconds = time.perf_counter() - t_alloc
             tick("alloc")
             status = torch.zeros(1, dtype=torch.int32, device=d)
             self.node_slots = torch.zeros((max(nnz, 1), 2), dtype=torch.int64, device=d)
