@@ -392,6 +392,7 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         comm_probe = c0.elapsed_time(c1) / 3e3
+    merges_timed = bool(mergers)
     del mergers
     stats = ctx.all_reduce_max(torch.tensor([t_total, t_walk, t_sgns], dtype=torch.float64, device=dev))
     sums = torch.tensor([float(steps_done.item()), float(model.pairs_trained())], dtype=torch.float64, device=dev)
@@ -501,8 +502,8 @@ def main():
         # N > 1 (rank 0's timers): seconds per step the compute stream spent in the merge phases, of which waiting
         # for the cold rows' all-reduce; overlap_fraction = share of that all-reduce's stand-alone cost that was
         # hidden under training
-        "merge_seconds": merge_secs["merge"] / K if world > 1 and mergers else None,       # None: not timed (graph replay)
-        "merge_wait_seconds": merge_secs["wait"] / K if world > 1 and mergers else None,
+        "merge_seconds": merge_secs["merge"] / K if world > 1 and merges_timed else None,       # None: not timed (graph replay)
+        "merge_wait_seconds": merge_secs["wait"] / K if world > 1 and merges_timed else None,
         "merges_per_step": (merge_secs["n"] / K if merge_secs["n"] else graph_mode.get("merges")) if world > 1 else None,
         # tsum without --merge-timers: one base interval captured as a HIP graph and replayed this many times per pass
         "merge_graph_replays_per_step": graph_mode["replays"] if world > 1 else None,
