@@ -1,3 +1,5 @@
+// LAB COPY (round 2) of csrc/n2v_walk_fat.hip with the A/B variants selected by N2V_WALK_VARIANT — not built into the
+// product library; see tools/lab/README.md.
 // "Fat slot" walk — gfx950 (MI355X): one 32-byte gather per step.
 //
 // Same walk as n2v_walk (src/node2vec.py:55-95, :271-281) over a table layout that spends
@@ -235,8 +237,8 @@ extern "C" int n2v_build_fat_slots(int64_t n_tables, const int64_t* tab_off, con
 extern "C" int n2v_walk_fat(const int64_t* row_ptr, const n2v_fat_slot* node_fat, const n2v_fat_slot* fat,
                             const int32_t* starts, int64_t n_starts, int64_t pos_begin, int64_t pos_count,
                             int64_t round_begin, int64_t round_count, int32_t walk_length, int32_t rng_mode,
-                            const double* uniforms, const int64_t* walk_uoff, uint64_t seed, int32_t* walks,
-                            int32_t* lens, void* stream) {
+                            const double* uniforms, const int64_t* walk_uoff, int64_t /*uoff_round_stride: product only*/,
+                            uint64_t seed, int32_t* walks, int32_t* lens, void* stream) {
     if (pos_count < 0 || round_count < 0 || pos_begin < 0 || round_begin < 0 || walk_length < 1 ||
         pos_begin + pos_count > n_starts)
         return n2v::fail(N2V_ERR_INVALID, "n2v_walk_fat: bad shard or length");

@@ -1,10 +1,10 @@
 """A/B of the fat-table walk kernel variants (N2V_WALK_VARIANT, csrc/n2v_walk_fat.hip) on C3 / C2: identical walks,
-HIP-event time per launch.  Also times preprocess phases.  Usage: python tools/walk_variant_probe.py [C3] [rounds]"""
+HIP-event time per launch.  Also times preprocess phases.  Usage (with a lab library, tools/lab/README.md): N2V_HIP_LIB=tools/lab/libn2v_hip_lab.so python tools/lab/walk_variant_probe.py [C3] [rounds]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "node2vec-by-ecc_amd"))
 import torch
 
