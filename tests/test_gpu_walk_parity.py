@@ -713,3 +713,17 @@ def test_randomised_parity_sweep(n2v):
             G = orc.OracleGraph(list(zip(src.tolist(), dst.tolist())), None if w is None else w.tolist(), directed)
             o = orc.Node2VecOracle(G, directed, p, q)
             assert o.simulate_walks(r, L, seed=seed, on_the_fly=True) == want, trial
+
+
+def test_degrees_on_the_lds_window_boundaries(n2v):
+    """Six graphs of tests/probes/boundary_stress.py (60 of them: profiles/r03/logs/boundary_stress_60_trials.log): hubs
+    whose degrees sit on the LDS-window boundaries of the table builder (512 slots) and of the on-the-fly kernel (256),
+    directed / weighted at random — every slot of the fat and thin tables, and the walks of the table kernel, the
+    on-the-fly kernel and the budgeted-table kernel (Philox and numpy streams), against the C oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+    import boundary_stress
+    rs = np.random.RandomState(7)
+    for t in range(6):
+        boundary_stress.trial(t, rs)
