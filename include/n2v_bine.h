@@ -72,7 +72,7 @@ int n2v_bine_walk(const int64_t* row_ptr, const int32_t* col, const int64_t* cum
                   const int32_t* walk_node, const int64_t* walk_off, int64_t n_walks, int64_t gw_base,
                   uint64_t seed, int32_t* tokens, void* stream);
 
-/* ---- negative pools (src/bine_lsh.py:22-51; datasketch MinHash LSH forest, absent offline) ----
+/* ---- negative pools, exact-Jaccard variant (role of src/bine_lsh.py:22-51 without the forest) ----
  * pool[v][s], s < pool_size (reference sample_num = 200): a vertex of v's own side
  * [side_lo, side_hi), drawn uniformly, redrawn (up to 16 times) while it is v itself or its
  * Jaccard similarity with v (over their rows) exceeds max_jaccard — the stand-in for "not
@@ -81,6 +81,47 @@ int n2v_bine_walk(const int64_t* row_ptr, const int32_t* col, const int64_t* cum
 int n2v_bine_neg_pools(const int64_t* row_ptr, const int32_t* col, int64_t side_lo, int64_t side_hi,
                        int64_t v_begin, int64_t v_end, int32_t pool_size, double max_jaccard,
                        uint64_t seed, int32_t* pool, void* stream);
+
+/* ---- negative pools, MinHash LSH forest (src/bine_lsh.py:7-51 on datasketch 1.2.5, requirements.txt:11) ----
+ * The reference builds MinHash(num_perm=128) of every vertex's neighbour labels, adds them to a
+ * MinHashLSHForest(num_perm=128) (l = 8 trees of k = 16 values), and for every not-yet-visited vertex i takes
+ * sim = forest.query(ms[i], 200); every unvisited vertex of sim joins i's cluster; the cluster's pool is a
+ * random.sample of 200 vertices from the side minus sim(i) and minus sim(j) of every j in sim(i)
+ * (src/bine_lsh.py:27-51).  The five steps below are that pipeline; ids are LOCAL to one side (0..n-1) except where
+ * said.  datasketch is absent offline: MinHash/LSHForest follow its published 1.2.5 source.
+ *
+ * n2v_lsh_sha1_labels: hv[i] = first four bytes (little endian) of SHA-1(label i) — datasketch MinHash.update's hash of
+ *   `d.encode('utf8')` (src/bine_lsh.py:16).  bytes: uint8[n][width] (label i in its first lens[i] bytes).
+ * n2v_lsh_minhash: sig[v - v_begin][j] = min over neighbours c of ((perm_a[j]*hv[c] + perm_b[j]) mod 2^64 mod (2^61-1))
+ *   & (2^32-1), 2^32-1 for an empty row; perm_a/perm_b: uint64[128] = datasketch's RandomState(1) parameters
+ *   (src/bine_lsh.py:14-16).  hv is indexed by the GLOBAL ids col holds.
+ * n2v_lsh_forest_query: forest.query(ms[v], k) for every v of the side (src/bine_lsh.py:38,46).  order: int32[8][n], tree
+ *   t's vertices sorted by their 16 values (ties by id = insertion order, src/bine_lsh.py:18); lo/hi: int32[n][8][16],
+ *   [v][t][r-1] = range of sorted positions of tree t sharing v's first r values.  sim: int32[n][k] receives the keys in
+ *   the order the forest yields new ones (r = 16..1, trees 0..7), sim_n their number (<= k; k <= 256).
+ * n2v_lsh_leader_round: one round of the `visted` sweep (src/bine_lsh.py:32-36,41-45).  rev_ptr/rev_src: CSR of
+ *   {l < i : i in sim(l)}, ascending l; owner: int32[n], -1 = unresolved on entry of the first round; a resolved
+ *   vertex holds the vertex whose turn produced its pool (itself = it has a turn).  unresolved (int32, device) is
+ *   incremented once per vertex still open; call until it stays 0.
+ * n2v_lsh_pools: pool rows of the vertices lead[0..n_lead) (owners of themselves): pool_size distinct vertices of the
+ *   side outside the exclusion set, drawn by Philox(seed; leader, round, lane) rejection in lane order, stored as
+ *   id_base + local id; when at most pool_size vertices are left, all of them ascending, then -1
+ *   (random.sample(total_list, min(sample_num, len(total_list))), src/bine_lsh.py:48).  pool: int32[n][pool_size], only
+ *   leaders' rows are written (followers copy their owner's row).  bitmap: uint32[n_groups][words_per_group], zero on
+ *   entry and on return, words_per_group >= ceil(n_side / 32).                                                   */
+#define N2V_LSH_NUM_PERM 128
+#define N2V_LSH_TREES 8
+int n2v_lsh_sha1_labels(const uint8_t* bytes, int32_t width, const int32_t* lens, int64_t n, uint32_t* hv,
+                        void* stream);
+int n2v_lsh_minhash(const int64_t* row_ptr, const int32_t* col, const uint32_t* hv, const uint64_t* perm_a,
+                    const uint64_t* perm_b, int64_t v_begin, int64_t v_end, uint32_t* sig, void* stream);
+int n2v_lsh_forest_query(const int32_t* order, const int32_t* lo, const int32_t* hi, int64_t n, int32_t k,
+                         int32_t* sim, int32_t* sim_n, void* stream);
+int n2v_lsh_leader_round(const int64_t* rev_ptr, const int32_t* rev_src, int64_t n, int32_t* owner,
+                         int32_t* unresolved, void* stream);
+int n2v_lsh_pools(const int32_t* sim, const int32_t* sim_n, int32_t k, const int32_t* lead, int64_t n_lead,
+                  int32_t n_side, int32_t pool_size, uint64_t seed, int32_t id_base, uint32_t* bitmap,
+                  int64_t words_per_group, int32_t n_groups, int32_t* pool, void* stream);
 
 /* ---- init_embedding_vectors (src/bine_train.py:183-206) ---------------------------------------
  * emb/ctx: fp64 [n][row_stride] (row_stride a multiple of 64 >= dim; padding stays 0).  Every
@@ -94,8 +135,8 @@ int n2v_bine_init(double* emb, double* ctx, int64_t n, int32_t dim, int32_t row_
  * visited_v dictionaries: a vertex is handled at its first rating, :462,475), then the KL update.
  * Skip-gram block of vertex c: min(#occurrences, 10) distinct occurrences of c in its side's
  * walks (random.sample, :465); per occurrence the window contexts z != c (window ws, within the
- * walk) and up to ns negatives — distinct slots of pool[c], dropped when inside the window or
- * repeated (src/bine_graph_utils.py:163-187) — then skip_gram(c, z, negs) for every z.
+ * walk) and up to ns negatives — distinct slots of pool[c], dropped when empty (-1: a pool shorter than pool_size),
+ * inside the window or repeated (src/bine_graph_utils.py:163-187) — then skip_gram(c, z, negs) for every z.
  * Occurrence index: occ_ptr int64[n+1], occ_pos int64[n_tokens] (token positions of each vertex,
  * ascending), tokens int32[n_tokens], tok_walk int32[n_tokens] (walk of each token), walk_off
  * int64[n_walks+1]; both sides in one token array (walks of users, then walks of items).

@@ -483,7 +483,7 @@ __device__ __forceinline__ void node_block(const TrainArgs& a, int32_t c, double
         for (int q = 0; q < NT - 1; ++q) {
             if (q < (int)m2) {
                 const int32_t cand = uni(__shfl(my_neg, q));
-                bool drop = __ballot(mytok == cand) != 0ull;  // in the window (src/bine_graph_utils.py:179-180)
+                bool drop = cand < 0 || __ballot(mytok == cand) != 0ull;  // empty slot; in the window (src/bine_graph_utils.py:179-180)
 #pragma unroll
                 for (int z = 0; z < NT; ++z) drop = drop || (z < nt && tgt[z] == cand);  // I_z is a dict: one entry per vertex
                 if (!drop) {

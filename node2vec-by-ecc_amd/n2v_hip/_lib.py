@@ -72,6 +72,11 @@ SIGNATURES = {
     "n2v_bine_walk_lengths": (C.c_int, [_ptr, _ptr, _ptr, _i64, _i64, _f64, _i32, _u64, _ptr, _ptr]),
     "n2v_bine_walk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _u64, _ptr, _ptr]),
     "n2v_bine_neg_pools": (C.c_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _f64, _u64, _ptr, _ptr]),
+    "n2v_lsh_sha1_labels": (C.c_int, [_ptr, _i32, _ptr, _i64, _ptr, _ptr]),
+    "n2v_lsh_minhash": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
+    "n2v_lsh_forest_query": (C.c_int, [_ptr, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _ptr]),
+    "n2v_lsh_leader_round": (C.c_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr]),
+    "n2v_lsh_pools": (C.c_int, [_ptr, _ptr, _i32, _ptr, _i64, _i32, _i32, _u64, _i32, _ptr, _i64, _i32, _ptr, _ptr]),
     "n2v_bine_init": (C.c_int, [_ptr, _ptr, _i64, _i32, _i32, _u64, _ptr]),
     "n2v_bine_train_pass": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _ptr,
                                       _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _f64, _ptr, _i32, _u64, _u64,

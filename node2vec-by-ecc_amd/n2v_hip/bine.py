@@ -267,19 +267,169 @@ class BineEngine:
         return [[self.g.label_of(int(t)) for t in tok[off[i]:off[i + 1]]] for i in range(lo, hi)]
 
     # ------------------------------------------------------------------ negatives, contexts
-    def build_negative_pools(self, pool_size=200, max_jaccard=1.0 / 128.0):
-        """get_negs (src/bine_graph_utils.py:145-148 -> src/bine_lsh.py:22-51): per vertex `pool_size` vertices of
-        its own side that are not similar to it.  The reference asks a MinHash LSH forest (128 permutations) for
-        the similar ones; here a candidate is refused when its exact Jaccard similarity exceeds `max_jaccard`
-        (default 1/128: less than one expected MinHash collision) — see DESIGN.md 4.7."""
+    def build_negative_pools(self, pool_size=200, max_jaccard=None, method=None, k=200):
+        """get_negs (src/bine_graph_utils.py:145-148 -> src/bine_lsh.py:22-51): per vertex up to `pool_size` vertices of
+        its own side that are not similar to it.
+
+        method="lsh" (default): the reference's pipeline — MinHash(128) signatures of the neighbour labels, a
+        MinHashLSHForest(l=8), `forest.query(ms[i], k)`, clusters of the `visted` sweep sharing one pool, the pool a
+        sample of the side minus sim(i) and sim(j), j in sim(i) (datasketch 1.2.5 restated).
+        method="jaccard" (chosen when `max_jaccard` is given): independent pools, a candidate refused when its exact
+        Jaccard similarity exceeds `max_jaccard` — the round-1 stand-in, kept for comparison."""
+        if method is None:
+            method = "jaccard" if max_jaccard is not None else "lsh"
+        if method == "lsh":
+            return self._build_lsh_pools(int(pool_size), int(k))
+        if method != "jaccard":
+            raise ValueError("method must be 'lsh' or 'jaccard'")
+        max_jaccard = 1.0 / 128.0 if max_jaccard is None else max_jaccard
         g, d, lib, p = self.g, self.device, self.lib, _lib.ptr
         with torch.cuda.device(d):
             pool = torch.empty((g.n, int(pool_size)), dtype=torch.int32, device=d)
-            for lo, hi, k in ((0, g.n_u, SEED_POOL_U), (g.n_u, g.n, SEED_POOL_V)):
+            for lo, hi, k_ in ((0, g.n_u, SEED_POOL_U), (g.n_u, g.n, SEED_POOL_V)):
                 if hi > lo:
                     _lib.check(lib.n2v_bine_neg_pools(p(self.row_ptr), p(self.col), lo, hi, lo, hi, int(pool_size),
-                                                      float(max_jaccard), self._seed(k), pool[lo:].data_ptr(),
+                                                      float(max_jaccard), self._seed(k_), pool[lo:].data_ptr(),
                                                       self._stream()))
+            self.pool = pool
+        return self
+
+    # -- MinHash LSH forest (include/n2v_bine.h, csrc/n2v_lsh.hip)
+    def label_hashes(self):
+        """hv[v] = datasketch's 32-bit SHA-1 value of vertex v's label as the reference feeds it to MinHash.update
+        (`d.encode('utf8')`, src/bine_lsh.py:16), computed on the device from the packed label bytes."""
+        g, d = self.g, self.device
+        labels = np.concatenate([np.asarray(g.user_labels).astype(str), np.asarray(g.item_labels).astype(str)])
+        raw = np.char.encode(labels, "utf8")                     # fixed-width 'S' array, zero padded
+        width = max(raw.dtype.itemsize, 1)
+        lens = np.char.str_len(raw).astype(np.int32)
+        mat = np.frombuffer(raw.tobytes(), dtype=np.uint8).reshape(len(labels), width) if len(labels) else np.zeros((0, 1), np.uint8)
+        with torch.cuda.device(d):
+            b = torch.from_numpy(np.array(mat)).to(d)
+            ln = torch.from_numpy(lens).to(d)
+            hv = torch.empty(g.n, dtype=torch.int32, device=d)   # uint32 bits
+            _lib.check(self.lib.n2v_lsh_sha1_labels(_lib.ptr(b), int(width), _lib.ptr(ln), g.n, _lib.ptr(hv), self._stream()))
+        return hv
+
+    @staticmethod
+    def minhash_permutations(num_perm=128, seed=1):
+        """datasketch 1.2.5 MinHash.__init__: (a_j, b_j) from numpy's legacy RandomState(seed), drawn alternately."""
+        gen = np.random.RandomState(seed)
+        m = (1 << 61) - 1
+        ab = np.array([(gen.randint(1, m, dtype=np.uint64), gen.randint(0, m, dtype=np.uint64)) for _ in range(num_perm)],
+                      dtype=np.uint64)
+        return np.ascontiguousarray(ab[:, 0]), np.ascontiguousarray(ab[:, 1])
+
+    def minhash_signatures(self, hv=None):
+        """int32 (uint32 bits) [n][128]: the MinHash of every vertex's neighbour set (src/bine_lsh.py:13-17)."""
+        g, d, p = self.g, self.device, _lib.ptr
+        hv = self.label_hashes() if hv is None else hv
+        a, b = self.minhash_permutations()
+        with torch.cuda.device(d):
+            pa = torch.from_numpy(a.view(np.int64)).to(d)
+            pb = torch.from_numpy(b.view(np.int64)).to(d)
+            sig = torch.empty((g.n, 128), dtype=torch.int32, device=d)
+            _lib.check(self.lib.n2v_lsh_minhash(p(self.row_ptr), p(self.col), p(hv), p(pa), p(pb), 0, g.n, p(sig), self._stream()))
+        return sig
+
+    def _forest_side(self, sig_side, k):
+        """One side's forest and all its queries.  torch: the eight sorted orders and the prefix ranges (sorts, scans);
+        HIP: the queries.  Returns (sim int32[n][k], sim_n int32[n])."""
+        d, p, lib = self.device, _lib.ptr, self.lib
+        n = int(sig_side.shape[0])
+        depth = 16
+        vals = sig_side.long() & 0xFFFFFFFF                       # unsigned order
+        idx = torch.arange(n, device=d)
+        order = torch.empty((8, n), dtype=torch.int32, device=d)
+        lo = torch.empty((n, 8, depth), dtype=torch.int32, device=d)
+        hi = torch.empty((n, 8, depth), dtype=torch.int32, device=d)
+        levels = torch.arange(1, depth + 1, device=d).unsqueeze(1)
+        for t in range(8):
+            s = vals[:, t * depth:(t + 1) * depth]
+            # two 32-bit values per signed 64-bit sort key, order preserved: ((a - 2^31) << 32) | b
+            pairs = ((s[:, 0::2] - (1 << 31)) << 32) | s[:, 1::2]
+            o = idx
+            for c in range(depth // 2 - 1, -1, -1):                 # lexicographic, stable: ties keep insertion order
+                o = o[torch.sort(pairs[o, c], stable=True).indices]
+            order[t] = o.int()
+            so = s[o]
+            lcp = torch.zeros(n, dtype=torch.int64, device=d)
+            if n > 1:
+                lcp[1:] = torch.cumprod((so[1:] == so[:-1]).long(), dim=1).sum(dim=1)
+            pos = torch.empty(n, dtype=torch.int64, device=d)
+            pos[o] = idx
+            cut = lcp.unsqueeze(0) < levels                         # [r-1][i]: a new prefix-r group starts at i (always at 0)
+            start = torch.cummax(torch.where(cut, idx.unsqueeze(0), torch.zeros_like(cut, dtype=torch.int64)), 1).values
+            nxt = torch.where(cut, idx.unsqueeze(0), torch.full_like(cut, n, dtype=torch.int64))
+            after = torch.flip(torch.cummin(torch.flip(nxt, [1]), 1).values, [1])       # first cut at or after i
+            end = torch.cat([after[:, 1:], torch.full((depth, 1), n, dtype=torch.int64, device=d)], 1)
+            lo[:, t, :] = start[:, pos].t().int()
+            hi[:, t, :] = end[:, pos].t().int()
+        sim = torch.empty((n, k), dtype=torch.int32, device=d)
+        sim_n = torch.empty(n, dtype=torch.int32, device=d)
+        _lib.check(lib.n2v_lsh_forest_query(p(order), p(lo), p(hi), n, k, p(sim), p(sim_n), self._stream()))
+        return sim, sim_n
+
+    def _cluster_owners(self, sim, sim_n):
+        """The `visted` sweep (src/bine_lsh.py:32-36,41-45): owner[i] = the vertex whose turn produced i's pool."""
+        d, p, lib = self.device, _lib.ptr, self.lib
+        n, k = int(sim.shape[0]), int(sim.shape[1])
+        src = torch.arange(n, device=d).unsqueeze(1).expand(n, k)
+        valid = (torch.arange(k, device=d).unsqueeze(0) < sim_n.unsqueeze(1)) & (sim.long() > src)
+        l, j = src[valid], sim.long()[valid]
+        key = torch.sort(j * n + l).values
+        rev_src = (key % n).int()
+        rev_ptr = torch.zeros(n + 1, dtype=torch.int64, device=d)
+        torch.cumsum(torch.bincount(key // n, minlength=n), 0, out=rev_ptr[1:])
+        owner = torch.full((n,), -1, dtype=torch.int32, device=d)
+        open_ = torch.zeros(1, dtype=torch.int32, device=d)
+        for _ in range(n + 1):
+            open_.zero_()
+            _lib.check(lib.n2v_lsh_leader_round(p(rev_ptr), p(rev_src), n, p(owner), p(open_), self._stream()))
+            if int(open_.item()) == 0:
+                break
+        else:
+            raise RuntimeError("n2v_lsh_leader_round: the sweep did not resolve")
+        return owner
+
+    def _build_lsh_pools(self, pool_size, k, groups=1024):
+        import time
+        g, d, p, lib = self.g, self.device, _lib.ptr, self.lib
+        secs = {"signatures": 0.0, "forest": 0.0, "clusters": 0.0, "pools": 0.0}
+
+        def lap(name, t0):
+            torch.cuda.synchronize(d)
+            secs[name] += time.perf_counter() - t0
+            return time.perf_counter()
+
+        with torch.cuda.device(d):
+            t = time.perf_counter()
+            sig = self.minhash_signatures()
+            t = lap("signatures", t)
+            pool = torch.full((g.n, pool_size), -1, dtype=torch.int32, device=d)
+            self.lsh = {}
+            for name, lo, hi, kseed in (("u", 0, g.n_u, SEED_POOL_U), ("v", g.n_u, g.n, SEED_POOL_V)):
+                n_side = hi - lo
+                if n_side <= 0:
+                    continue
+                t = time.perf_counter()
+                sim, sim_n = self._forest_side(sig[lo:hi], k)
+                t = lap("forest", t)
+                owner = self._cluster_owners(sim, sim_n)
+                lead = torch.nonzero(owner == torch.arange(n_side, device=d, dtype=torch.int32)).flatten().int()
+                t = lap("clusters", t)
+                words = (n_side + 31) // 32
+                n_groups = int(min(groups, max(int(lead.shape[0]), 1)))
+                bitmap = torch.zeros((n_groups, words), dtype=torch.int32, device=d)
+                side_pool = pool[lo:hi]
+                _lib.check(lib.n2v_lsh_pools(p(sim), p(sim_n), k, p(lead), int(lead.shape[0]), n_side, pool_size,
+                                             self._seed(kseed), lo, p(bitmap), words, n_groups, side_pool.data_ptr(),
+                                             self._stream()))
+                side_pool.copy_(side_pool[owner.long()])            # every member of a cluster holds its owner's pool
+                t = lap("pools", t)
+                self.lsh[name] = dict(sim=sim, sim_n=sim_n, owner=owner, clusters=int(lead.shape[0]))
+            self.lsh["signatures"] = sig
+            self.lsh["seconds"] = secs
             self.pool = pool
         return self
 

@@ -208,7 +208,7 @@ def sample_occurrences(c, n_occ, iteration, seed_occ):
 def occurrence_context(o, c, tokens, tok_walk, walk_off, pool_row, ws, ns, seed_neg):
     """Contexts and negatives of the occurrence at token position o of vertex c
     (src/bine_graph_utils.py:169-187: window within the walk, tokens equal to the centre skipped; negatives
-    = distinct pool slots, dropped when inside the window or repeated)."""
+    = distinct pool slots, dropped when empty, inside the window or repeated)."""
     wk = int(tok_walk[o])
     w0, w1 = int(walk_off[wk]), int(walk_off[wk + 1])
     s, e = max(w0, o - ws), min(w1, o + ws + 1)
@@ -219,7 +219,7 @@ def occurrence_context(o, c, tokens, tok_walk, walk_off, pool_row, ws, ns, seed_
     negs = []
     for slot in floyd_sample(len(pool_row), m2, words):
         cand = int(pool_row[slot])
-        if cand in window or cand in negs or cand == c:
+        if cand < 0 or cand in window or cand in negs or cand == c:   # -1: empty slot of a short pool
             continue
         negs.append(cand)
     return contexts, negs

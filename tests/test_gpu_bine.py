@@ -241,7 +241,9 @@ def test_two_rank_probe_over_gloo(tmp_path):
     j1 = json.loads(one.stdout.strip().splitlines()[-1])
     j2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert j2["n_gpus"] == 2 and j1["walks"] == j2["walks"]
-    assert np.allclose(j1["train"]["losses"], j2["train"]["losses"], rtol=5e-3)
+    # 1e-2: LSH clusters share one pool (src/bine_lsh.py:49-51), so negatives collide across the two shards more often than
+    # independent pools did (0.5 % apart on this graph)
+    assert np.allclose(j1["train"]["losses"], j2["train"]["losses"], rtol=1e-2)
     # the overlapped merge (the other rank's changes arrive one pass late): same walks, a loss curve close to the
     # synchronous one on this graph — the pass's own loss is reduced at once, only the tables lag
     port2 = 29600 + os.getpid() % 300

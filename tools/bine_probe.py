@@ -81,6 +81,13 @@ def run(args, ctx=None, emit=True):
     timed("walks", lambda: e.generate_walks(0.15, args.maxT, 1))
     out["walks"] = {"n_walks_u": e.n_walks[0], "n_walks_v": e.n_walks[1], "tokens": int(e.tokens.shape[0])}
     timed("neg_pools", lambda: e.build_negative_pools(args.pool))
+    if getattr(e, "lsh", None):
+        out["neg_pools_lsh"] = {"seconds": e.lsh["seconds"], "clusters_u": e.lsh.get("u", {}).get("clusters"),
+                                "clusters_v": e.lsh.get("v", {}).get("clusters"),
+                                "mean_query_size_u": float(e.lsh["u"]["sim_n"].float().mean().item()) if "u" in e.lsh else None,
+                                "mean_query_size_v": float(e.lsh["v"]["sim_n"].float().mean().item()) if "v" in e.lsh else None}
+        if ctx.rank == 0:
+            print("[bine] lsh", out["neg_pools_lsh"], file=sys.stderr, flush=True)
     timed("occurrences", e.build_occurrences)
     timed("init", lambda: e.init_embeddings(args.dim))
     timed("train_warmup", lambda: run(max_iter=max(1, args.warmup_iters), max_blocks=args.max_blocks, mode=args.mode))
