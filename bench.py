@@ -186,6 +186,7 @@ def bench_bine(args):
                    if ctx.world > 1 else "single GPU"},
         "stages_seconds": {k[:-2]: v for k, v in out.items() if k.endswith("_s") and not k.startswith("train")},
         "hits_iterations": out["hits_iterations"], "losses": tr["losses"][-K:],
+        "negative_pools": {"method": "MinHash LSH forest (src/bine_lsh.py; datasketch 1.2.5 restated)", **out.get("neg_pools_lsh", {})},
         "roofline": {"kernel": "bine_train_kernel", "bound": "hbm", "achieved": bytes_launch / launch_s / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / launch_s / 1e9 / HBM_PEAK_GBS,
                      "traffic": (traffic or {}).get("bine_train_kernel"),

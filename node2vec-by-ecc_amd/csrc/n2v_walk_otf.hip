@@ -16,6 +16,8 @@
 // The table lives in the wave's slice of LDS while K <= kLdsSlots (256) and in a per-wave global
 // scratch row of max_degree slots otherwise.  Serial chains of many waves interleave on a
 // SIMD, so throughput comes from occupancy; -ffp-contract=off keeps every rounding separate.
+#include <cstdlib>
+
 #include "n2v_common.h"
 #include "n2v_wave_table.h"
 
@@ -49,6 +51,9 @@ struct OtfArgs {
     int32_t* walks;
     int32_t* lens;
     int32_t* status;
+    // draw before building (n2v_wave_table.h): 1 = after the weights and their sum, 2 = dyadic counting first
+    int32_t draw_first;
+    double wp, wq;            // 1/p, 1/q
 };
 
 template <bool HYBRID>
@@ -108,15 +113,22 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
                 K = uni((int)(deg_hi & 0xFFFFFFu));
                 arr = a.fat;
             } else {
-                bool ok;
-                ws.row_n = n2v::wave_cache_row(a.g, my_row, prev, lane);     // has_edge(nbr, prev): prev's row, staged in LDS
-                if (K <= kLdsSlots) ok = n2v::wave_build_table(a.g, Tl, ws, prev, base, K, lane);
-                else ok = n2v::wave_build_table(a.g, Tg, ws, prev, base, K, lane);
-                if (!ok) { failed = true; break; }
-                double qk; int Jk;
-                if (K <= kLdsSlots) { qk = Tl[kk].q; Jk = Tl[kk].J; }
-                else { qk = Tg[kk].q; Jk = Tg[kk].J; }
-                const int pick = (u2 < qk) ? kk : Jk;  // :278-281
+                int pick = kk;
+                ws.row_n = n2v::wave_cache_row(a.g, my_row, prev, lane);      // has_edge(nbr, prev): prev's row, staged in LDS
+                bool drawn = a.draw_first == 2 && n2v::dyadic_accepts(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, lane);
+                if (!drawn) {
+                    n2v_alias_slot* T = K <= kLdsSlots ? Tl : Tg;
+                    double norm;
+                    if (!n2v::wave_weights_and_norm(a.g, T, ws, prev, base, K, lane, norm)) { failed = true; break; }
+                    if (a.draw_first == 1) {     // slot kk `smaller` (its q is final, :253-255) and accepted (:278)?
+                        const double q0 = (double)K * (T[kk].q / norm);
+                        drawn = q0 < 1.0 && u2 < q0;
+                    }
+                    if (!drawn) {
+                        n2v::wave_finish_table(T, K, norm, lane);
+                        pick = (u2 < T[kk].q) ? kk : T[kk].J;  // :278-281
+                    }
+                }
                 prev = cur;
                 if (HYBRID) {
                     const uint4 r = *reinterpret_cast<const uint4*>(a.recs + base + pick);   // {slot_lo, base, dst, deg_hi}
@@ -176,8 +188,13 @@ int launch_otf(const char* who, bool hybrid, const int64_t* row_ptr, const int32
         if (fit < 1) return n2v::fail(N2V_ERR_INVALID, "%s: scratch smaller than 4 x max_degree slots", who);
         if (blocks > fit) blocks = fit;
     }
+    // dyadic counting (n2v_wave_table.h): unweighted, undirected, 1/p and 1/q multiples of 2^-20 up to 2^10, degrees < 2^21
+    const double wp = 1.0 / p, wq = 1.0 / q;
+    auto dyadic = [](double x) { return x > 0.0 && x <= 1024.0 && x * 1048576.0 == (double)(int64_t)(x * 1048576.0); };
+    int32_t draw_first = (!w && symmetric && dyadic(wp) && dyadic(wq) && max_degree < (1 << 21)) ? 2 : 1;
+    if (const char* e = getenv("N2V_OTF_DRAW_FIRST")) draw_first = atoi(e) < draw_first ? atoi(e) : draw_first;
     OtfArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
-              rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, node_fat, fat, recs, walks, lens, status};
+              rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, node_fat, fat, recs, walks, lens, status, draw_first, wp, wq};
     if (hybrid) hipLaunchKernelGGL(walk_otf_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(walk_otf_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return n2v::check_launch(who);

@@ -295,6 +295,113 @@ __device__ __forceinline__ bool wave_build_table(const RowCtx& a, Slot* T, const
     return true;
 }
 
+// ---- draw before building (on-the-fly walk) ------------------------------------------------------------------------
+// alias_setup only ever rewrites q[large] (:264): a slot it classifies as `smaller` (q = K * prob < 1, :253-255) keeps
+// that q for good.  When the step's first uniform lands on such a slot kk and the second accepts it (u2 < q[kk], :278),
+// alias_draw returns kk without looking at J or at any other slot: the step needs the K weights, their left-to-right
+// sum and ONE division — not the classification, the stacks or the pairing (54-60 % of a table's cycles, tab_stamps).
+// wave_weights_and_norm = phases 1-2 of wave_build_table; wave_finish_table = phases 3-4.
+template <typename Slot>
+__device__ __forceinline__ bool wave_weights_and_norm(const RowCtx& a, Slot* T, const WaveScratch ws, int32_t src, int64_t base,
+                                                      int K, int lane, double& norm_out) {
+    for (int k = lane; k < K; k += 64) T[k].q = step_weight(a, ws, src, base, k);
+    wave_sync();
+    double norm = 0.0;
+    for (int c = 0; c < K; c += 64)
+        norm = wave_sum_in_order(ws, norm, (c + lane < K) ? T[c + lane].q : 0.0, min(64, K - c), lane);
+    norm_out = unid(norm);
+    return norm_out != 0.0;
+}
+template <typename Slot>
+__device__ __forceinline__ void wave_finish_table(Slot* T, int K, double norm, int lane) {
+    const double Kd = (double)K;
+    int ns = 0, nl = 0;
+    for (int c = 0; c < K; c += 64) {
+        const int k = c + lane;
+        const bool valid = k < K;
+        double qk = 0.0;
+        if (valid) {
+            qk = Kd * (T[k].q / norm);
+            T[k].q = qk;
+            T[k].J = 0;
+        }
+        const bool is_small = valid && (qk < 1.0);
+        const unsigned long long ms = __ballot(is_small), ml = __ballot(valid && !is_small);
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        if (is_small) T[ns + __popcll(ms & below)].aux = k;
+        else if (valid) T[K - (nl + __popcll(ml & below) + 1)].aux = k;
+        ns += __popcll(ms);
+        nl += __popcll(ml);
+    }
+    ns = uni(ns);
+    nl = uni(nl);
+    wave_sync();
+    AosSink<Slot> sink{T, lane};
+    wave_pair(AosTable<Slot>{T}, sink, K, ns, nl, lane);
+    wave_sync();
+}
+
+// Unweighted undirected graphs whose 1/p and 1/q are dyadic (multiples of 2^-20 up to 2^10; degrees below 2^21): every
+// weight is one of {1/p, 1, 1/q}, every partial sum of the reference's left-to-right sum (:149) is a multiple of 2^-20
+// below 2^32 — exact in fp64 — so the sum does not depend on the order and equals
+//     [prev in row(cur)] * 1/p  +  n_adj * 1  +  (K - [prev in row(cur)] - n_adj) * 1/q,     each product and sum exact,
+// with n_adj = |{x in row(cur): x != prev, x in row(prev)}| (has_edge(x, prev) on an undirected graph, :145).  The count
+// walks the SHORTER of the two sorted rows and searches the longer one; no table, no LDS, no serial chain.
+__device__ __forceinline__ bool sorted_contains(const int32_t* __restrict__ row, int n, int32_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < n && row[lo] == v;
+}
+// true: slot kk is `smaller` and u2 accepts it — the step goes to col[base + kk].  ws.row / ws.row_n: prev's row staged in
+// LDS (wave_cache_row) or row_n < 0.
+__device__ __forceinline__ bool dyadic_accepts(const RowCtx& a, const WaveScratch& ws, int32_t prev, int64_t base, int K, int kk,
+                                               double u2, double wp, double wq, int lane) {
+    double wk = 1.0, norm = (double)K;       // first step: the node table, all weights 1 (:184-188)
+    if (prev >= 0) {
+        const int64_t pb = uni64(a.row_ptr[prev]);
+        const int S = uni((int)(a.row_ptr[prev + 1] - pb));
+        const int32_t* rc = a.col + base;
+        const int32_t* rp = a.col + pb;
+        const bool cached = ws.row_n >= 0;   // == S
+        int n_adj = 0, n_prev = 0;
+        if (K <= S || (cached && K <= 8 * S)) {   // walk cur's row, search prev's (in LDS when staged)
+            for (int c = 0; c < K; c += 64) {
+                const int k = c + lane;
+                bool adj = false, isp = false;
+                if (k < K) {
+                    const int32_t nb = rc[k];
+                    isp = nb == prev;
+                    adj = !isp && (cached ? lds_row_contains(ws.row, S, nb) : sorted_contains(rp, S, nb));
+                }
+                n_adj += __popcll(__ballot(adj));
+                n_prev += __popcll(__ballot(isp));
+            }
+        } else {                                  // walk prev's row, search cur's
+            for (int c = 0; c < S; c += 64) {
+                const int i = c + lane;
+                bool adj = false;
+                if (i < S) {
+                    const int32_t x = cached ? ws.row[i] : rp[i];
+                    adj = x != prev && sorted_contains(rc, K, x);
+                }
+                n_adj += __popcll(__ballot(adj));
+            }
+            n_prev = sorted_contains(rc, K, prev) ? 1 : 0;
+        }
+        n_adj = uni(n_adj);
+        n_prev = uni(n_prev);
+        const int32_t nbk = uni(rc[kk]);
+        wk = nbk == prev ? wp : ((cached ? lds_row_contains(ws.row, S, nbk) : sorted_contains(rp, S, nbk)) ? 1.0 : wq);
+        norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;
+    }
+    const double qk = (double)K * (wk / norm);
+    return qk < 1.0 && u2 < qk;
+}
+
 // ---- large tables of the table BUILDER: nothing but the two stacks is stored ---------------------------------------
 // A table too large for the wave's LDS slots used to be built in place in its output (q, J and the stack words landed
 // as partial-line writes in the 32-B fat slots before the final slot was written: 2.65x the output in write traffic on

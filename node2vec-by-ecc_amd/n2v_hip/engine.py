@@ -35,7 +35,10 @@ class WalkEngine:
         d = self.device
         self.row_ptr = torch.from_numpy(csr.row_ptr).to(d)
         self.col = torch.from_numpy(csr.col).to(d)
-        self.w = None if csr.w is None else torch.from_numpy(csr.w).to(d)
+        # all-ones weights ARE the unweighted graph (`G[u][v]['weight'] = 1` of src/main.py:48-49): the kernels then use 1.0
+        # without loading it — same bits — and the on-the-fly walk may count instead of summing (n2v_wave_table.h)
+        unit = csr.w is not None and bool(np.all(csr.w == 1.0))
+        self.w = None if (csr.w is None or unit) else torch.from_numpy(csr.w).to(d)
         self.start_order = torch.from_numpy(csr.start_order).to(d)
         self.deg = (self.row_ptr[1:] - self.row_ptr[:-1])
         hdeg = np.diff(csr.row_ptr)
