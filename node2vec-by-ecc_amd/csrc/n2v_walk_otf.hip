@@ -115,18 +115,26 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
             } else {
                 int pick = kk;
                 ws.row_n = n2v::wave_cache_row(a.g, my_row, prev, lane);      // has_edge(nbr, prev): prev's row, staged in LDS
-                bool drawn = a.draw_first == 2 && n2v::dyadic_accepts(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, lane);
-                if (!drawn) {
-                    n2v_alias_slot* T = K <= kLdsSlots ? Tl : Tg;
-                    double norm;
-                    if (!n2v::wave_weights_and_norm(a.g, T, ws, prev, base, K, lane, norm)) { failed = true; break; }
-                    if (a.draw_first == 1) {     // slot kk `smaller` (its q is final, :253-255) and accepted (:278)?
-                        const double q0 = (double)K * (T[kk].q / norm);
-                        drawn = q0 < 1.0 && u2 < q0;
-                    }
+                if (K <= 64 && a.draw_first) {                                // the table in registers, one slot per lane
+                    pick = n2v::wave_draw_le64(a.g, ws, prev, base, K, kk, u2, a.draw_first == 2, lane);
+                    if (pick < 0) { failed = true; break; }
+                } else {
+                    bool drawn = a.draw_first == 2 && n2v::dyadic_accepts(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, lane);
+#ifdef N2V_OTF_LAB_ALWAYS_ACCEPT   /* timing ceiling of the fast path only: WRONG walks */
+                    drawn = true;
+#endif
                     if (!drawn) {
-                        n2v::wave_finish_table(T, K, norm, lane);
-                        pick = (u2 < T[kk].q) ? kk : T[kk].J;  // :278-281
+                        n2v_alias_slot* T = K <= kLdsSlots ? Tl : Tg;
+                        double norm;
+                        if (!n2v::wave_weights_and_norm(a.g, T, ws, prev, base, K, lane, norm)) { failed = true; break; }
+                        if (a.draw_first == 1) {     // slot kk `smaller` (its q is final, :253-255) and accepted (:278)?
+                            const double q0 = (double)K * (T[kk].q / norm);
+                            drawn = q0 < 1.0 && u2 < q0;
+                        }
+                        if (!drawn) {
+                            n2v::wave_finish_table(T, K, norm, lane);
+                            pick = (u2 < T[kk].q) ? kk : T[kk].J;  // :278-281
+                        }
                     }
                 }
                 prev = cur;

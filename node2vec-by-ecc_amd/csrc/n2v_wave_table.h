@@ -402,6 +402,67 @@ __device__ __forceinline__ bool dyadic_accepts(const RowCtx& a, const WaveScratc
     return qk < 1.0 && u2 < qk;
 }
 
+// Rows of at most 64 neighbours (84 % of the steps of a walk on a power-law graph, and nearly all whose slot kk is NOT
+// accepted at once): the whole table lives in registers, one slot per lane — no LDS table, no index stacks.  The two
+// stacks are two lane masks (both were pushed in index order, so the top of either is its highest set bit, :252-257,
+// 260-261), a slot's q is a v_readlane away, and the sweep stops as soon as slot kk is final: a small is final when it
+// is popped (:263 gives its J; its q never changed), a large when `smaller` runs dry or — after it dropped below 1 —
+// when the next large absorbs it; slots the sweep never reaches keep q and J = 0 (:248).  Returns the slot alias_draw
+// picks (:277-281) or -1 when the weights sum to 0 (:150, ZeroDivisionError).
+//   exact_sum: every partial sum is exact (dyadic weights, see above) — the butterfly sum equals the left-to-right one.
+__device__ __forceinline__ int wave_draw_le64(const RowCtx& a, const WaveScratch& ws, int32_t src, int64_t base, int K, int kk,
+                                              double u2, bool exact_sum, int lane) {
+    const bool valid = lane < K;
+    const double w = valid ? step_weight(a, ws, src, base, lane) : 0.0;
+    double norm;
+    if (exact_sum) {
+        norm = w;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const int lo = __shfl_xor(__double2loint(norm), s), hi = __shfl_xor(__double2hiint(norm), s);
+            norm = norm + __hiloint2double(hi, lo);
+        }
+    } else {
+        norm = wave_sum_in_order(ws, 0.0, w, K, lane);
+    }
+    norm = unid(norm);
+    if (norm == 0.0) return -1;
+    const double q = (double)K * (w / norm);                     // :150 then :253
+    unsigned long long ms = __ballot(valid && q < 1.0), ml = __ballot(valid && !(q < 1.0));
+    double q_kk = readlane_f64(q, kk);
+    if (((ms >> kk) & 1ULL) && u2 < q_kk) return kk;             // `smaller` and accepted: nothing else matters
+    int J_kk = 0;
+    bool carried = false, done = false;
+    int c_i = 0;
+    double c_q = 0.0;
+    while (!done && ml != 0ULL && (carried || ms != 0ULL)) {     // :259
+        const int large = 63 - __builtin_clzll(ml);               // larger.pop()
+        ml &= ~(1ULL << large);
+        double ql = readlane_f64(q, large);
+        for (;;) {
+            int small;
+            double qs;
+            if (carried) { small = c_i; qs = c_q; carried = false; }
+            else if (ms != 0ULL) { small = 63 - __builtin_clzll(ms); ms &= ~(1ULL << small); qs = readlane_f64(q, small); }
+            else {                                                // `smaller` is dry: the large stays with its current q
+                if (large == kk) q_kk = ql;
+                done = true;
+                break;
+            }
+            if (small == kk) { J_kk = large; q_kk = qs; done = true; break; }   // :263 — slot kk is final
+            ql = ql + qs;                                         // :264, left to right
+            ql = ql - 1.0;
+            if (uni((int)(ql < 1.0))) {                           // :265-266 — the large is the next small
+                if (ml == 0ULL) { if (large == kk) q_kk = ql; done = true; }    // nothing left to absorb it: J stays 0
+                else { carried = true; c_i = large; c_q = ql; }
+                break;
+            }
+            if (large == kk && ms == 0ULL) { q_kk = ql; done = true; break; }   // back on `larger`, `smaller` dry
+        }
+    }
+    return (u2 < q_kk) ? kk : J_kk;                               // :278-281
+}
+
 // ---- large tables of the table BUILDER: nothing but the two stacks is stored ---------------------------------------
 // A table too large for the wave's LDS slots used to be built in place in its output (q, J and the stack words landed
 // as partial-line writes in the 32-B fat slots before the final slot was written: 2.65x the output in write traffic on

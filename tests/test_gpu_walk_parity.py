@@ -277,10 +277,18 @@ def test_on_the_fly_kernel_matches_reference(n2v, name):
     assert w1 == o.node2vec_walk(9, z["nodes"].tolist()[0], np.random.RandomState(5).random_sample, on_the_fly=True)
 
 
-@pytest.mark.parametrize("weighted,directed,p,q", [(False, False, 0.25, 4.0), (True, True, 0.5, 2.0)])
+@pytest.mark.parametrize("weighted,directed,p,q", [
+    (False, False, 0.25, 4.0),   # dyadic 1/p, 1/q on an unweighted undirected graph: the counting path (n2v_wave_table.h)
+    (False, False, 1.0, 1.0),    # dyadic, every class weight 1
+    (False, False, 4.0, 0.5),    # dyadic, the return slot small and the far slots large
+    (False, False, 0.3, 0.7),    # not dyadic: weights summed left to right, draw before the pairing
+    (True, False, 0.25, 4.0),    # weighted: general path
+    (False, True, 0.25, 4.0),    # directed: has_edge(nbr, prev) is not a row intersection -> general path
+    (True, True, 0.5, 2.0)])
 def test_on_the_fly_kernel_equals_table_walk_with_hubs(n2v, weighted, directed, p, q):
     """20k nodes plus hubs of degree 700 and 3000 (tables beyond the 512-slot LDS window go
-    through the global scratch path): on-the-fly walks == table-driven walks, bit for bit."""
+    through the global scratch path; a hub as `prev` is a row too long for the LDS row cache, a hub as `cur` makes the
+    counting path walk prev's row instead): on-the-fly walks == table-driven walks, bit for bit."""
     import torch
     rs = np.random.RandomState(11)
     n, m = 20000, 80000

@@ -1,0 +1,12 @@
+# Builds A/B variants of the on-the-fly walk kernel into tools/lab/_ab/ (run in the build container; the .so files travel).
+set -e
+cd "$(dirname "$0")/../../node2vec-by-ecc_amd/csrc"
+make -s
+mkdir -p ../../tools/lab/_ab
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I../../include"
+OTHERS=$(ls _obj/*.o | grep -v n2v_walk_otf.o)
+build() { name=$1; shift; /opt/rocm/bin/hipcc $FLAGS "$@" -c n2v_walk_otf.hip -o /tmp/otf_$name.o && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/lab/_ab/lib_$name.so /tmp/otf_$name.o $OTHERS; }
+build lds128 -DN2V_OTF_LDS_SLOTS=128
+build lds64 -DN2V_OTF_LDS_SLOTS=64
+build accept -DN2V_OTF_LAB_ALWAYS_ACCEPT
+ls -la ../../tools/lab/_ab
