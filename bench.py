@@ -440,6 +440,20 @@ def main():
                  "seconds_each": times, "uniform_layout": "tiled (64 walks x step-major), one chunk"}
         del corpus
         g.rng = "philox"
+    # the reference's memory-saving mode (ON_THE_FLY = True, src/settings.py:18, is main_link's default): no stored edge
+    # tables, every step rebuilds — or proves it does not need — its alias table (one round of the same walks, N=1)
+    otf = None
+    if world == 1 and not args.no_reference_exact:
+        eng.walk_on_the_fly(eng.start_order, 1, L, rng="philox", seed=3)      # warm-up (scratch rows)
+        o0, o1 = ev(), ev()
+        o0.record()
+        _, ol = eng.walk_on_the_fly(eng.start_order, 1, L, rng="philox", seed=4)
+        o1.record()
+        torch.cuda.synchronize()
+        otf = {"metric": "walk-steps/s, on-the-fly tables (src/node2vec.py:97-111: no stored edge tables)",
+               "value": float((ol.long() - 1).sum().item()) / (o0.elapsed_time(o1) / 1e3), "unit": "walk-steps/s",
+               "seconds": o0.elapsed_time(o1) / 1e3, "rounds": 1}
+        del ol
     if rank != 0:
         ctx.close()
         return
@@ -493,6 +507,7 @@ def main():
         "walk": {"steps_per_step_global": steps_all / K, "seconds_per_step": t_walk / K,
                  "table_layout": "fat (32-B slots)" if eng.edge_fat is not None else "thin (16-B slots + records)"},
         "walk_reference_exact": exact,
+        "walk_on_the_fly": otf,
         "sgns_shared_negatives": shared,
         # first call in this process, of which the table allocation (hipMalloc, host-blocking when the driver hands out
         # memory some allocation has just released), the rest (kernels + index plumbing), and a second call on the

@@ -27,7 +27,8 @@ namespace {
 #define N2V_OTF_LDS_SLOTS 256   /* 6 KiB per wave -> 6 workgroups per CU: C3 2.1 -> 2.6e8 steps/s vs 512 slots / 4 workgroups; 128: 2.5e8 */
 #endif
 constexpr int kLdsSlots = N2V_OTF_LDS_SLOTS;  // 16 B per slot and wave, plus the feed and row cache of n2v_wave_table.h
-constexpr int kLdsPerWg = 4 * (kLdsSlots * 16 + n2v::kFeed * 8 + n2v::kRowCache * 4);
+constexpr int kOtfRow = 256;   // two row buffers per wave: the row of `prev` (searched) and the row of `cur` (it is the next step's `prev`)
+constexpr int kLdsPerWg = 4 * (kLdsSlots * 16 + n2v::kFeed * 8 + 2 * kOtfRow * 4);
 constexpr int kWgPerCu = (160 * 1024 / kLdsPerWg) < 8 ? (160 * 1024 / kLdsPerWg) : 8;
 
 using n2v::uni;
@@ -60,14 +61,17 @@ template <bool HYBRID>
 __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
     __shared__ n2v_alias_slot lds[4 * kLdsSlots];
     __shared__ double feed[4 * n2v::kFeed];
-    __shared__ int32_t rows[4 * n2v::kRowCache];
+    __shared__ int32_t rows[4 * 2 * kOtfRow];
     const int lane = threadIdx.x & 63;
     // the wave index is the same in all 64 lanes: tell the compiler, so that everything derived from
     // it (walk id, loop bounds, table sizes) is scalar and loops branch on SCC instead of EXEC
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     n2v_alias_slot* Tl = lds + wv * kLdsSlots;
-    int32_t* my_row = rows + wv * n2v::kRowCache;
-    n2v::WaveScratch ws{feed + wv * n2v::kFeed, my_row, -1};
+    int32_t* my_rows = rows + wv * 2 * kOtfRow;
+    n2v::WaveScratch ws{feed + wv * n2v::kFeed, my_rows, -1};
+    int pb = 0;                 // which of the wave's two row buffers holds the row of `cached_node`
+    int32_t cached_node = -1;
+    int cached_n = -1;
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
     n2v_alias_slot* Tg = a.scratch + wave_global * a.max_degree;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -114,9 +118,30 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
                 arr = a.fat;
             } else {
                 int pick = kk;
-                ws.row_n = n2v::wave_cache_row(a.g, my_row, prev, lane);      // has_edge(nbr, prev): prev's row, staged in LDS
+                // has_edge(nbr, prev) searches prev's row in LDS.  It was `cur` one step ago, so the row staged then is
+                // reused; it is fetched only after a stored-table step (hybrid) or when it did not fit.
+                int32_t* P = my_rows + pb * kOtfRow;
+                int32_t* C = my_rows + (pb ^ 1) * kOtfRow;
+                if (prev >= 0 && a.g.symmetric) {
+                    if (cached_node != prev) { cached_n = n2v::wave_cache_row(a.g, P, prev, lane, kOtfRow); cached_node = prev; }
+                    ws.row = P;
+                    ws.row_n = cached_n;
+                } else {
+                    ws.row_n = -1;
+                }
+                const int Kc = K;                                           // (the hybrid step below overwrites K)
+                const int32_t nb0 = lane < K ? a.g.col[base + lane] : -1;   // the row's first 64 entries, one per lane
+                const bool staged = a.g.symmetric && K <= kOtfRow;
+                if (staged) {
+                    if (lane < K) C[lane] = nb0;
+                    for (int i = 64 + lane; i < K; i += 64) C[i] = a.g.col[base + i];
+                    n2v::wave_sync();
+                }
                 if (K <= 64 && a.draw_first) {                                // the table in registers, one slot per lane
-                    pick = n2v::wave_draw_le64(a.g, ws, prev, base, K, kk, u2, a.draw_first == 2, lane);
+                    pick = n2v::wave_draw_le64(a.g, ws, prev, base, nb0, K, kk, u2, a.draw_first == 2, a.wp, a.wq, lane);
+#ifdef N2V_OTF_LAB_ALWAYS_ACCEPT
+                    pick = pick < 0 ? pick : kk;
+#endif
                     if (pick < 0) { failed = true; break; }
                 } else {
                     bool drawn = a.draw_first == 2 && n2v::dyadic_accepts(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, lane);
@@ -145,8 +170,11 @@ __global__ void __launch_bounds__(256) walk_otf_kernel(OtfArgs a) {
                     K = uni((int)(r.w & 0xFFFFFFu));
                     arr = a.fat;
                 } else {
-                    cur = uni(a.g.col[base + pick]);
+                    cur = K <= 64 ? __builtin_amdgcn_readlane(nb0, uni(pick)) : staged ? uni(C[pick]) : uni(a.g.col[base + pick]);
                 }
+                pb ^= 1;                          // the staged row is the next step's prev row
+                cached_node = staged ? prev : -1;
+                cached_n = Kc;
                 __builtin_amdgcn_wave_barrier();  // the table is rebuilt in place on the next step
             }
             if (lane == 0) out[len] = cur;
@@ -189,6 +217,9 @@ int launch_otf(const char* who, bool hybrid, const int64_t* row_ptr, const int32
     // grid: as many resident waves as the scratch rows allow (4 workgroups of 4 waves per CU by LDS)
     int64_t blocks = (n_local + 3) / 4;
     if (blocks > 256 * kWgPerCu) blocks = 256 * kWgPerCu;   // every resident workgroup slot (LDS-bound), once
+#ifdef N2V_OTF_LAB_GRID_DIV
+    blocks = (blocks + N2V_OTF_LAB_GRID_DIV - 1) / N2V_OTF_LAB_GRID_DIV;
+#endif
     if (max_degree > kLdsSlots) {
         if (!scratch) return n2v::fail(N2V_ERR_INVALID, "%s: scratch needed (max degree %lld > %d)", who,
                                        (long long)max_degree, kLdsSlots);

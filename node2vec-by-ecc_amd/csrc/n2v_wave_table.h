@@ -63,11 +63,11 @@ struct WaveScratch {
 };
 
 // fills ws_row[0..S) with row(src) when it fits; returns the row_n to pass on (all lanes call it)
-__device__ __forceinline__ int wave_cache_row(const RowCtx& a, int32_t* ws_row, int32_t src, int lane) {
+__device__ __forceinline__ int wave_cache_row(const RowCtx& a, int32_t* ws_row, int32_t src, int lane, int cap = kRowCache) {
     if (src < 0 || !a.symmetric) return -1;
     const int64_t b = uni64(a.row_ptr[src]);
     const int S = uni((int)(a.row_ptr[src + 1] - b));
-    if (S > kRowCache) return -1;
+    if (S > cap) return -1;
     for (int i = lane; i < S; i += 64) ws_row[i] = a.col[b + i];
     wave_sync();
     return S;
@@ -84,14 +84,15 @@ __device__ __forceinline__ bool lds_row_contains(const int32_t* row, int n, int3
 }
 
 // unnormalised transition weight of neighbour k of the row at `base` for a step arriving from `src` (:142-148)
-__device__ __forceinline__ double step_weight(const RowCtx& a, const WaveScratch& ws, int32_t src, int64_t base, int k) {
-    const int32_t nb = a.col[base + k];
-    const double wt = a.w ? a.w[base + k] : 1.0;
+__device__ __forceinline__ double step_weight_of(const RowCtx& a, const WaveScratch& ws, int32_t src, int32_t nb, double wt) {
     if (src < 0) return wt;
     if (nb == src) return wt / a.p;
     const bool adj = ws.row_n >= 0 ? lds_row_contains(ws.row, ws.row_n, nb)
                      : a.symmetric ? row_contains(a.row_ptr, a.col, src, nb) : row_contains(a.row_ptr, a.col, nb, src);
     return adj ? wt : wt / a.q;
+}
+__device__ __forceinline__ double step_weight(const RowCtx& a, const WaveScratch& ws, int32_t src, int64_t base, int k) {
+    return step_weight_of(a, ws, src, a.col[base + k], a.w ? a.w[base + k] : 1.0);
 }
 
 // norm = norm + v[0] + v[1] + ... strictly left to right (:149): the wave's 64 values are parked in LDS and added in
@@ -410,27 +411,35 @@ __device__ __forceinline__ bool dyadic_accepts(const RowCtx& a, const WaveScratc
 // when the next large absorbs it; slots the sweep never reaches keep q and J = 0 (:248).  Returns the slot alias_draw
 // picks (:277-281) or -1 when the weights sum to 0 (:150, ZeroDivisionError).
 //   exact_sum: every partial sum is exact (dyadic weights, see above) — the butterfly sum equals the left-to-right one.
-__device__ __forceinline__ int wave_draw_le64(const RowCtx& a, const WaveScratch& ws, int32_t src, int64_t base, int K, int kk,
-                                              double u2, bool exact_sum, int lane) {
+//   nb: the lane's neighbour col[base + lane] (lanes < K), already loaded by the caller.
+//   wp, wq: 1/p, 1/q (used when exact_sum: the weight classes are lane masks and the sum is a count, as in dyadic_accepts).
+// Slot kk is tested BEFORE the other lanes normalise (one fp64 division instead of 64 lanes' worth of them).
+__device__ __forceinline__ int wave_draw_le64(const RowCtx& a, const WaveScratch& ws, int32_t src, int64_t base, int32_t nb, int K,
+                                              int kk, double u2, bool exact_sum, double wp, double wq, int lane) {
     const bool valid = lane < K;
-    const double w = valid ? step_weight(a, ws, src, base, lane) : 0.0;
-    double norm;
+    double w, norm, w_kk;
     if (exact_sum) {
-        norm = w;
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-            const int lo = __shfl_xor(__double2loint(norm), s), hi = __shfl_xor(__double2hiint(norm), s);
-            norm = norm + __hiloint2double(hi, lo);
+        const bool isp = valid && src >= 0 && nb == src;
+        const bool adj = valid && src >= 0 && !isp &&
+                         (ws.row_n >= 0 ? lds_row_contains(ws.row, ws.row_n, nb) : row_contains(a.row_ptr, a.col, src, nb));
+        const unsigned long long mp = __ballot(isp), ma = __ballot(adj);
+        if (src < 0) { norm = (double)K; w_kk = 1.0; w = 1.0; }      // the node table: all weights 1 (:184-188)
+        else {
+            const int n_prev = __popcll(mp), n_adj = __popcll(ma);
+            norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;   // exact, see dyadic_accepts
+            w_kk = ((mp >> kk) & 1ULL) ? wp : (((ma >> kk) & 1ULL) ? 1.0 : wq);
+            w = isp ? wp : (adj ? 1.0 : wq);
         }
     } else {
-        norm = wave_sum_in_order(ws, 0.0, w, K, lane);
+        w = valid ? step_weight_of(a, ws, src, nb, a.w ? a.w[base + lane] : 1.0) : 0.0;
+        norm = unid(wave_sum_in_order(ws, 0.0, w, K, lane));
+        if (norm == 0.0) return -1;
+        w_kk = readlane_f64(w, kk);
     }
-    norm = unid(norm);
-    if (norm == 0.0) return -1;
-    const double q = (double)K * (w / norm);                     // :150 then :253
+    double q_kk = (double)K * (w_kk / norm);                     // :150 then :253
+    if (q_kk < 1.0 && u2 < q_kk) return kk;                      // `smaller` and accepted: nothing else matters
+    const double q = valid ? (double)K * (w / norm) : 0.0;
     unsigned long long ms = __ballot(valid && q < 1.0), ml = __ballot(valid && !(q < 1.0));
-    double q_kk = readlane_f64(q, kk);
-    if (((ms >> kk) & 1ULL) && u2 < q_kk) return kk;             // `smaller` and accepted: nothing else matters
     int J_kk = 0;
     bool carried = false, done = false;
     int c_i = 0;
