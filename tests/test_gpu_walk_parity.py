@@ -665,6 +665,40 @@ def test_directed_sinks_sharded_and_pass_bound(n2v):
     assert g2.stream_passes < 0.35 * W, (g2.stream_passes, W)
 
 
+@pytest.mark.parametrize("weighted,p,q", [(False, 0.25, 4.0), (True, 0.5, 2.0), (False, 0.3, 0.7)])
+def test_budgeted_walk_lane_kernel_equals_table_walk(n2v, weighted, p, q):
+    """Launches of >= ~2e5 walks of a partially stored engine run the lane-per-walk kernel (n2v_walk_otf.hip: stored steps
+    per lane, rebuild steps served by the whole wave); smaller ones — every other budget test — the wave-per-walk one.
+    240k walks on the 20k-node hub graph at a third of the tables, Philox (64-B bursts, L = 16) and numpy stream (L = 13:
+    single-id writes), against the fully stored tables."""
+    import torch
+    rs = np.random.RandomState(12)
+    n, m = 20000, 80000
+    src = np.concatenate([rs.randint(0, n, size=m), np.full(700, 5), np.full(3000, 17)])
+    dst = np.concatenate([rs.randint(0, n, size=m), rs.choice(n, 700, replace=False), rs.choice(n, 3000, replace=False)])
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    w = (rs.randint(1, 9, len(src)) / 2.0) if weighted else None
+    from n2v_hip import csr
+    cg = csr.from_edges(src, dst, w, False)
+    g = n2v.Graph.from_csr(cg, p, q, rng="philox", seed=5)
+    g.preprocess_transition_probs()
+    full = g._engine.total_slots * 32
+    a = g.simulate_walks(12, 16)
+    g.rng = "numpy"
+    np.random.seed(9)
+    a2 = g.simulate_walks(12, 13)
+    g.preprocess_transition_probs(budget_bytes=full // 3)
+    assert g._engine.partial and int((~g._engine.stored_mask).sum()) > 0
+    g.rng = "philox"
+    b = g.simulate_walks(12, 16)
+    assert torch.equal(a.lens, b.lens) and torch.equal(a.walks, b.walks)
+    g.rng = "numpy"
+    np.random.seed(9)
+    b2 = g.simulate_walks(12, 13)
+    assert torch.equal(a2.lens, b2.lens) and torch.equal(a2.walks, b2.walks)
+
+
 def test_randomised_parity_sweep(n2v):
     """40 random small graphs (directed or not, weighted or not, self-loops, isolated targets,
     duplicate lines, p and q from a grid incl. 1): tables and reference-exact walks vs the C oracle

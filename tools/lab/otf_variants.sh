@@ -10,4 +10,6 @@ build lds128 -DN2V_OTF_LDS_SLOTS=128
 build accept -DN2V_OTF_LAB_ALWAYS_ACCEPT
 build halfgrid -DN2V_OTF_LAB_GRID_DIV=2
 build quartergrid -DN2V_OTF_LAB_GRID_DIV=4
+build build_always -DN2V_OTF_LAB_DRAW_FIRST=0
+build sum_always -DN2V_OTF_LAB_DRAW_FIRST=1
 ls -la ../../tools/lab/_ab
