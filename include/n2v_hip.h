@@ -205,11 +205,16 @@ int n2v_mt19937_fill_tiled(const uint32_t* states, int32_t n_streams, int32_t po
 /* simulate_walks_on_the_fly / node2vec_walk_on_the_fly (src/node2vec.py:13-53,97-111): the
  * same walk with the (prev, cur) table rebuilt at every step instead of read from the edge
  * tables (for graphs whose sum of deg^2 slots does not fit in HBM).  Output is identical to
- * n2v_walk under the same uniforms.  One wavefront per walk; tables of up to 512 slots are
- * built in LDS, larger ones in `scratch` (n2v_alias_slot[scratch_slots]; the launch uses
- * floor(scratch_slots / max_degree) wavefronts, at least 4 are required when
- * max_degree > 512; may be NULL otherwise).  status: int32[1], N2V_STATUS_ZERO_NORM on a
- * zero-sum neighbourhood.  Other arguments as n2v_walk.                                   */
+ * n2v_walk under the same uniforms.  One wavefront per walk.  A step first asks whether it needs
+ * the table at all: a slot that alias_setup classifies as `smaller` keeps q = K * prob (:253-255;
+ * only q[large] is rewritten, :264), so when slot int(u1*K) is such a slot and u2 < q (:278) the
+ * step only needs the weights' left-to-right sum — which on an unweighted undirected graph with
+ * dyadic 1/p, 1/q (w == NULL, symmetric, multiples of 2^-20 up to 2^10) is an exact count of
+ * common neighbours; rows of at most 64 neighbours are otherwise paired in registers, larger
+ * tables of up to n2v_walk_otf_lds_slots() slots in LDS, the rest in `scratch`
+ * (n2v_alias_slot[scratch_slots]; the launch uses floor(scratch_slots / max_degree) wavefronts,
+ * at least 4 are required when max_degree exceeds the LDS window; may be NULL otherwise).
+ * status: int32[1], N2V_STATUS_ZERO_NORM on a zero-sum neighbourhood.  Other arguments as n2v_walk. */
 /* Largest table the on-the-fly / hybrid kernels build in LDS, and the most wavefronts a launch uses (= scratch rows). */
 int32_t n2v_walk_otf_lds_slots(void);
 int32_t n2v_walk_otf_max_waves(void);
@@ -226,8 +231,9 @@ int n2v_walk_on_the_fly(const int64_t* row_ptr, const int32_t* col, const double
  * caller stores fat tables for a subset of the CSR entries (n2v_build_edge_recs with negative offsets for the others,
  * n2v_build_edge_tables_wave over an `order` list of the stored ones); a step that arrives through a stored entry is
  * one gather as in n2v_walk_fat, any other step rebuilds its table as n2v_walk_on_the_fly does.  Same walks, bit for
- * bit.  One wavefront per walk.  node_fat: fat node tables (first step); fat / recs as for n2v_walk_fat; scratch as
- * for n2v_walk_on_the_fly.                                                                                        */
+ * bit.  Large launches run one LANE per walk (stored steps as in n2v_walk_fat; the wave serves its lanes' rebuild steps
+ * one after the other), small ones one wavefront per walk.  node_fat: fat node tables (first step); fat / recs as for
+ * n2v_walk_fat; scratch as for n2v_walk_on_the_fly.                                                                */
 int n2v_walk_hybrid(const int64_t* row_ptr, const int32_t* col, const double* w, double p, double q, int32_t symmetric,
                     int64_t max_degree, const struct n2v_fat_slot* node_fat, const struct n2v_fat_slot* fat,
                     const n2v_edge_rec* recs, const int32_t* starts, int64_t n_starts, int64_t pos_begin,
