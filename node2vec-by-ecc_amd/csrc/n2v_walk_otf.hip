@@ -99,7 +99,8 @@ struct OtfWave {
 #endif
             if (pk < 0) return -1;
         } else {
-            bool drawn = a.draw_first == 2 && n2v::dyadic_accepts(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, lane);
+            bool drawn = a.draw_first == 2 && n2v::dyadic_accepts(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, reinterpret_cast<int32_t*>(Tl),
+                                                                      kLdsSlots * 4, lane);
 #ifdef N2V_OTF_LAB_ALWAYS_ACCEPT
             drawn = true;
 #endif

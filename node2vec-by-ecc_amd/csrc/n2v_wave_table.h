@@ -357,10 +357,44 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* __restrict__ row,
     }
     return lo < n && row[lo] == v;
 }
+// A long sorted row searched by the lanes of one wave.  Binary searches in global memory are log2(n) DEPENDENT loads each
+// (a hub row of thousands: ~8 us); here the row is first copied into `big` (LDS, `cap` ints) with pipelined coalesced
+// loads when it fits, else every stride-th element is (pivots): a search is LDS probes plus at most log2(stride)
+// dependent loads inside one segment.
+struct StagedRow {
+    const int32_t* g;      // the row in global memory
+    const int32_t* big;    // LDS: the row (stride 1) or its pivots g[0], g[stride], g[2 stride], ...
+    int n, stride, n_big;
+    __device__ __forceinline__ bool contains(int32_t v) const {
+        int lo = 0, hi = n_big;                       // first staged entry >= v
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (big[mid] < v) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < n_big && big[lo] == v) return true;
+        if (stride == 1 || lo == 0) return false;
+        int glo = (lo - 1) * stride + 1, ghi = min(lo * stride, n);   // strictly between pivots lo-1 and lo
+        while (glo < ghi) {
+            const int mid = (glo + ghi) >> 1;
+            if (g[mid] < v) glo = mid + 1;
+            else ghi = mid;
+        }
+        return glo < min(lo * stride, n) && g[glo] == v;
+    }
+};
+__device__ __forceinline__ StagedRow stage_row(const int32_t* __restrict__ g, int n, int32_t* big, int cap, int lane) {
+    const int stride = (n + cap - 1) / cap;           // 1 when the row fits
+    const int n_big = (n + stride - 1) / stride;
+    for (int i = lane; i < n_big; i += 64) big[i] = g[(int64_t)i * stride];
+    wave_sync();
+    return StagedRow{g, big, n, stride, n_big};
+}
+
 // true: slot kk is `smaller` and u2 accepts it — the step goes to col[base + kk].  ws.row / ws.row_n: prev's row staged in
-// LDS (wave_cache_row) or row_n < 0.
+// LDS (wave_cache_row) or row_n < 0.  big/cap: LDS scratch for the longer row (the table window, unused until a build).
 __device__ __forceinline__ bool dyadic_accepts(const RowCtx& a, const WaveScratch& ws, int32_t prev, int64_t base, int K, int kk,
-                                               double u2, double wp, double wq, int lane) {
+                                               double u2, double wp, double wq, int32_t* big, int cap, int lane) {
     double wk = 1.0, norm = (double)K;       // first step: the node table, all weights 1 (:184-188)
     if (prev >= 0) {
         const int64_t pb = uni64(a.row_ptr[prev]);
@@ -368,36 +402,58 @@ __device__ __forceinline__ bool dyadic_accepts(const RowCtx& a, const WaveScratc
         const int32_t* rc = a.col + base;
         const int32_t* rp = a.col + pb;
         const bool cached = ws.row_n >= 0;   // == S
+        const int32_t nbk = uni(rc[kk]);
         int n_adj = 0, n_prev = 0;
-        if (K <= S || (cached && K <= 8 * S)) {   // walk cur's row, search prev's (in LDS when staged)
+        bool k_adj = false;                  // nbk in row(prev)
+        if (cached && K <= 8 * S) {          // walk cur's row, search prev's in its LDS copy
             for (int c = 0; c < K; c += 64) {
                 const int k = c + lane;
                 bool adj = false, isp = false;
                 if (k < K) {
                     const int32_t nb = rc[k];
                     isp = nb == prev;
-                    adj = !isp && (cached ? lds_row_contains(ws.row, S, nb) : sorted_contains(rp, S, nb));
+                    adj = !isp && lds_row_contains(ws.row, S, nb);
                 }
                 n_adj += __popcll(__ballot(adj));
                 n_prev += __popcll(__ballot(isp));
             }
-        } else {                                  // walk prev's row, search cur's
+            k_adj = lds_row_contains(ws.row, S, nbk);
+        } else if (K <= S) {                 // walk cur's row, search prev's long row
+            const StagedRow R = stage_row(rp, S, big, cap, lane);
+            for (int c = 0; c < K; c += 64) {
+                const int k = c + lane;
+                bool adj = false, isp = false;
+                if (k < K) {
+                    const int32_t nb = rc[k];
+                    isp = nb == prev;
+                    adj = !isp && R.contains(nb);
+                }
+                n_adj += __popcll(__ballot(adj));
+                n_prev += __popcll(__ballot(isp));
+            }
+            k_adj = R.contains(nbk);
+        } else {                             // walk prev's row, search cur's long row
+            const StagedRow R = stage_row(rc, K, big, cap, lane);
+            unsigned long long hit_k = 0ULL;
             for (int c = 0; c < S; c += 64) {
                 const int i = c + lane;
                 bool adj = false;
+                int32_t x = -1;
                 if (i < S) {
-                    const int32_t x = cached ? ws.row[i] : rp[i];
-                    adj = x != prev && sorted_contains(rc, K, x);
+                    x = cached ? ws.row[i] : rp[i];
+                    adj = x != prev && R.contains(x);
                 }
                 n_adj += __popcll(__ballot(adj));
+                hit_k |= __ballot(x == nbk);
             }
-            n_prev = sorted_contains(rc, K, prev) ? 1 : 0;
+            n_prev = R.contains(prev) ? 1 : 0;
+            k_adj = hit_k != 0ULL;
         }
         n_adj = uni(n_adj);
         n_prev = uni(n_prev);
-        const int32_t nbk = uni(rc[kk]);
-        wk = nbk == prev ? wp : ((cached ? lds_row_contains(ws.row, S, nbk) : sorted_contains(rp, S, nbk)) ? 1.0 : wq);
+        wk = nbk == prev ? wp : (k_adj ? 1.0 : wq);
         norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;
+        wave_sync();                         // `big` is the table window: done with it before a build starts
     }
     const double qk = (double)K * (wk / norm);
     return qk < 1.0 && u2 < qk;
