@@ -99,8 +99,12 @@ struct OtfWave {
 #endif
             if (pk < 0) return -1;
         } else {
-            bool drawn = a.draw_first == 2 && n2v::dyadic_accepts(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, reinterpret_cast<int32_t*>(Tl),
-                                                                      kLdsSlots * 4, lane);
+            bool drawn = false;
+            if (a.draw_first == 2) {         // dyadic weights: the pick from counts and a sweep over the three weight classes
+                const int d = n2v::dyadic_draw(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, reinterpret_cast<int32_t*>(Tl),
+                                               kLdsSlots * 4, reinterpret_cast<int32_t*>(ws.feed), lane);
+                if (d >= 0) { pk = d; drawn = true; }   // -2: more common neighbours than the sweep's list holds -> build
+            }
 #ifdef N2V_OTF_LAB_ALWAYS_ACCEPT
             drawn = true;
 #endif
@@ -367,12 +371,12 @@ int launch_otf(const char* who, bool hybrid, const int64_t* row_ptr, const int32
         int64_t lblocks = (n_local + 255) / 256;
         if (lblocks > blocks) lblocks = blocks;
         const dim3 grid((unsigned)lblocks), block(256);
-        const int burst = (walk_length % 16 == 0 && ((uintptr_t)walks & 63) == 0) ? 16
-                          : (walk_length % 4 == 0 && ((uintptr_t)walks & 15) == 0) ? 4 : 1;
+        // 16-B output pieces: the 64-B bursts of the table-driven kernel cost 30 VGPRs here (4 instead of 6 waves per SIMD)
+        // and this kernel lives on the waves it keeps in flight (C3, a third of the tables: 5.6 -> 6.3e9 steps/s)
+        const int burst = (walk_length % 4 == 0 && ((uintptr_t)walks & 15) == 0) ? 4 : 1;
 #define N2V_LAUNCH_LANES(RNG)                                                                                       \
         do {                                                                                                        \
-            if (burst == 16) hipLaunchKernelGGL((walk_hybrid_lanes_kernel<RNG, 16>), grid, block, 0, st, a);        \
-            else if (burst == 4) hipLaunchKernelGGL((walk_hybrid_lanes_kernel<RNG, 4>), grid, block, 0, st, a);     \
+            if (burst == 4) hipLaunchKernelGGL((walk_hybrid_lanes_kernel<RNG, 4>), grid, block, 0, st, a);          \
             else hipLaunchKernelGGL((walk_hybrid_lanes_kernel<RNG, 1>), grid, block, 0, st, a);                     \
         } while (0)
         if (rng_mode == N2V_RNG_UNIFORMS) N2V_LAUNCH_LANES(N2V_RNG_UNIFORMS);

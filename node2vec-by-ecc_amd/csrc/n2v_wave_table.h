@@ -365,23 +365,25 @@ struct StagedRow {
     const int32_t* g;      // the row in global memory
     const int32_t* big;    // LDS: the row (stride 1) or its pivots g[0], g[stride], g[2 stride], ...
     int n, stride, n_big;
-    __device__ __forceinline__ bool contains(int32_t v) const {
+    __device__ __forceinline__ int find(int32_t v) const {   // position of v in the row, -1 if absent
         int lo = 0, hi = n_big;                       // first staged entry >= v
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (big[mid] < v) lo = mid + 1;
             else hi = mid;
         }
-        if (lo < n_big && big[lo] == v) return true;
-        if (stride == 1 || lo == 0) return false;
-        int glo = (lo - 1) * stride + 1, ghi = min(lo * stride, n);   // strictly between pivots lo-1 and lo
+        if (lo < n_big && big[lo] == v) return lo * stride;
+        if (stride == 1 || lo == 0) return -1;
+        const int top = min(lo * stride, n);
+        int glo = (lo - 1) * stride + 1, ghi = top;   // strictly between pivots lo-1 and lo
         while (glo < ghi) {
             const int mid = (glo + ghi) >> 1;
             if (g[mid] < v) glo = mid + 1;
             else ghi = mid;
         }
-        return glo < min(lo * stride, n) && g[glo] == v;
+        return (glo < top && g[glo] == v) ? glo : -1;
     }
+    __device__ __forceinline__ bool contains(int32_t v) const { return find(v) >= 0; }
 };
 __device__ __forceinline__ StagedRow stage_row(const int32_t* __restrict__ g, int n, int32_t* big, int cap, int lane) {
     const int stride = (n + cap - 1) / cap;           // 1 when the row fits
@@ -391,72 +393,177 @@ __device__ __forceinline__ StagedRow stage_row(const int32_t* __restrict__ g, in
     return StagedRow{g, big, n, stride, n_big};
 }
 
-// true: slot kk is `smaller` and u2 accepts it — the step goes to col[base + kk].  ws.row / ws.row_n: prev's row staged in
-// LDS (wave_cache_row) or row_n < 0.  big/cap: LDS scratch for the longer row (the table window, unused until a build).
-__device__ __forceinline__ bool dyadic_accepts(const RowCtx& a, const WaveScratch& ws, int32_t prev, int64_t base, int K, int kk,
-                                               double u2, double wp, double wq, int32_t* big, int cap, int lane) {
-    double wk = 1.0, norm = (double)K;       // first step: the node table, all weights 1 (:184-188)
-    if (prev >= 0) {
-        const int64_t pb = uni64(a.row_ptr[prev]);
-        const int S = uni((int)(a.row_ptr[prev + 1] - pb));
-        const int32_t* rc = a.col + base;
-        const int32_t* rp = a.col + pb;
-        const bool cached = ws.row_n >= 0;   // == S
-        const int32_t nbk = uni(rc[kk]);
-        int n_adj = 0, n_prev = 0;
-        bool k_adj = false;                  // nbk in row(prev)
-        if (cached && K <= 8 * S) {          // walk cur's row, search prev's in its LDS copy
-            for (int c = 0; c < K; c += 64) {
-                const int k = c + lane;
-                bool adj = false, isp = false;
-                if (k < K) {
-                    const int32_t nb = rc[k];
-                    isp = nb == prev;
-                    adj = !isp && lds_row_contains(ws.row, S, nb);
-                }
-                n_adj += __popcll(__ballot(adj));
-                n_prev += __popcll(__ballot(isp));
+// The whole draw of a dyadic step, any K: alias_draw's pick (:277-281) without a table.
+//  1. count (above) — and note WHERE in cur's row the special slots sit: prev's (weight 1/p) and the common neighbours'
+//     (weight 1), ascending, in `spec` (LDS, kSpecCap ints; more common neighbours than that: returns -2 and the caller
+//     builds the table).  Every other slot weighs 1/q.
+//  2. q takes three values, one per class — K * (w_class / norm), the builder's two roundings — so a class is `smaller`
+//     or `larger` as a whole; if slot kk is smaller and u2 < q it is the pick (98 % of the draws on a hub row).
+//  3. otherwise Vose's sweep (:259-268) is replayed on the CLASSES: both stacks were pushed in index order, so each is a
+//     descending walk over the indices of its classes (jumping from special to special when the 1/q class is on the other
+//     stack); the chain of fp64 adds is the reference's, operand by operand; it stops when slot kk is final, as in
+//     wave_draw_le64.  No table, no stacks, no memory traffic beyond `spec`: a rejected draw on a row of thousands costs
+//     ~20 us instead of the ~240 us of building its table.
+// ws.row / ws.row_n: prev's row staged in LDS (wave_cache_row) or row_n < 0.  big/cap: LDS scratch for the longer row
+// (the table window, unused until a build).
+constexpr int kSpecCap = 128;
+struct ClassSweep {
+    const int32_t* M;      // the special slots, ascending: position * 4 + class (1 = weight 1, 2 = 1/p); every other slot: class 0 (1/q)
+    int m;
+    int smask;             // bit cl: class cl is `smaller`
+    double qv;             // lane cl holds the class's q (read by v_readlane: no indexed memory)
+    __device__ __forceinline__ bool sm(int cl) const { return (smask >> cl) & 1; }
+    __device__ __forceinline__ double qc(int cl) const { return readlane_f64(qv, uni(cl)); }
+};
+// One of Vose's two stacks as a descending sequence of RUNS: a special slot (one index) or the gap of 1/q slots between
+// two specials (all of one class, so all on the same stack) — a hub row of thousands is a handful of runs.
+struct RunIter {
+    int j, top;            // next special (index into M, descending), highest index not yet covered
+    int want;              // 1: the `smaller` stack, 0: the `larger` one
+    int r_top, r_cnt, r_cls;   // current run: indices r_top, r_top-1, ... (r_cnt of them; 0 = the stack is empty)
+    __device__ __forceinline__ void next(const ClassSweep& c) {
+        for (;;) {
+            if (top < 0) { r_cnt = 0; return; }
+            const int e = j >= 0 ? uni(c.M[j]) : -4;
+            const int spos = e >> 2;
+            if (spos == top) {
+                --j;
+                r_top = top; r_cnt = 1; r_cls = e & 3;
+                --top;
+            } else {
+                r_top = top; r_cnt = top - spos; r_cls = 0;
+                top = spos;
             }
-            k_adj = lds_row_contains(ws.row, S, nbk);
-        } else if (K <= S) {                 // walk cur's row, search prev's long row
-            const StagedRow R = stage_row(rp, S, big, cap, lane);
-            for (int c = 0; c < K; c += 64) {
-                const int k = c + lane;
-                bool adj = false, isp = false;
-                if (k < K) {
-                    const int32_t nb = rc[k];
-                    isp = nb == prev;
-                    adj = !isp && R.contains(nb);
-                }
-                n_adj += __popcll(__ballot(adj));
-                n_prev += __popcll(__ballot(isp));
-            }
-            k_adj = R.contains(nbk);
-        } else {                             // walk prev's row, search cur's long row
-            const StagedRow R = stage_row(rc, K, big, cap, lane);
-            unsigned long long hit_k = 0ULL;
-            for (int c = 0; c < S; c += 64) {
-                const int i = c + lane;
-                bool adj = false;
-                int32_t x = -1;
-                if (i < S) {
-                    x = cached ? ws.row[i] : rp[i];
-                    adj = x != prev && R.contains(x);
-                }
-                n_adj += __popcll(__ballot(adj));
-                hit_k |= __ballot(x == nbk);
-            }
-            n_prev = R.contains(prev) ? 1 : 0;
-            k_adj = hit_k != 0ULL;
+            if ((int)c.sm(r_cls) == want) return;
         }
-        n_adj = uni(n_adj);
-        n_prev = uni(n_prev);
-        wk = nbk == prev ? wp : (k_adj ? 1.0 : wq);
-        norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;
-        wave_sync();                         // `big` is the table window: done with it before a build starts
     }
-    const double qk = (double)K * (wk / norm);
-    return qk < 1.0 && u2 < qk;
+    __device__ __forceinline__ void take(const ClassSweep& c, int n) {   // n <= r_cnt entries popped
+        r_top -= n;
+        r_cnt -= n;
+        if (r_cnt == 0) next(c);
+    }
+};
+__device__ __forceinline__ int dyadic_draw(const RowCtx& a, const WaveScratch& ws, int32_t prev, int64_t base, int K, int kk,
+                                           double u2, double wp, double wq, int32_t* big, int cap, int32_t* spec, int lane) {
+    if (prev < 0) {                          // first step: the node table, all weights 1 (:184-188): one class, no pairing
+        const double q = (double)K * (1.0 / (double)K);
+        return (u2 < q) ? kk : 0;
+    }
+    const int64_t pb = uni64(a.row_ptr[prev]);
+    const int S = uni((int)(a.row_ptr[prev + 1] - pb));
+    const int32_t* rc = a.col + base;
+    const int32_t* rp = a.col + pb;
+    const bool cached = ws.row_n >= 0;       // == S
+    int n_adj = 0, p_idx = -1;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    auto note = [&](bool adj, int pos) {     // append the positions of this chunk's common neighbours (ascending already)
+        const unsigned long long m = __ballot(adj);
+        const int at = n_adj + __popcll(m & below);
+        if (adj && at < kSpecCap) spec[at] = pos;     // (beyond the list: counted, and the caller builds the table)
+        n_adj += __popcll(m);
+    };
+    if ((cached && K <= 8 * S) || K <= S) {  // walk cur's row, search prev's (its LDS copy, or staged now)
+        StagedRow R{rp, ws.row, S, 1, S};
+        if (!cached) R = stage_row(rp, S, big, cap, lane);
+        for (int c = 0; c < K; c += 64) {
+            const int k = c + lane;
+            bool adj = false, isp = false;
+            if (k < K) {
+                const int32_t nb = rc[k];
+                isp = nb == prev;
+                adj = !isp && R.contains(nb);
+            }
+            note(adj, k);
+            const unsigned long long mp = __ballot(isp);
+            if (mp != 0ULL) p_idx = c + __builtin_ctzll(mp);
+        }
+    } else {                                 // walk prev's row, find its entries in cur's long row
+        const StagedRow R = stage_row(rc, K, big, cap, lane);
+        for (int c = 0; c < S; c += 64) {
+            const int i = c + lane;
+            int pos = -1;
+            if (i < S) {
+                const int32_t x = cached ? ws.row[i] : rp[i];
+                if (x != prev) pos = R.find(x);
+            }
+            note(pos >= 0, pos);
+        }
+        p_idx = R.find(prev);
+    }
+    n_adj = uni(n_adj);
+    p_idx = uni(p_idx);
+    wave_sync();                             // spec is read below; `big` is the table window: done with it
+    const int n_prev = p_idx >= 0 ? 1 : 0;
+    const int m = n_adj + n_prev;
+    if (m > kSpecCap) return -2;
+    // spec -> M: tag the common neighbours with class 1 and insert prev's slot (class 2) at its place
+    {
+        const int v0 = lane < n_adj ? spec[lane] : 0x3FFFFFFF, v1 = 64 + lane < n_adj ? spec[64 + lane] : 0x3FFFFFFF;
+        const int before = __popcll(__ballot(v0 < p_idx)) + __popcll(__ballot(v1 < p_idx));   // p_idx = -1: 0
+        wave_sync();
+        if (lane < n_adj) spec[lane + ((n_prev && v0 > p_idx) ? 1 : 0)] = v0 * 4 + 1;
+        if (64 + lane < n_adj) spec[64 + lane + ((n_prev && v1 > p_idx) ? 1 : 0)] = v1 * 4 + 1;
+        if (n_prev && lane == 0) spec[before] = p_idx * 4 + 2;
+        wave_sync();
+    }
+    const double norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;   // exact (see above)
+    const double Kd = (double)K;
+    const double q0 = Kd * (wq / norm), q1 = Kd * (1.0 / norm), q2 = Kd * (wp / norm);
+    const ClassSweep c{spec, m, (q0 < 1.0 ? 1 : 0) | (q1 < 1.0 ? 2 : 0) | (q2 < 1.0 ? 4 : 0),
+                       lane == 0 ? q0 : (lane == 1 ? q1 : q2)};
+    int cls_kk = 0;
+    {
+        const int e0 = lane < m ? spec[lane] : -4, e1 = 64 + lane < m ? spec[64 + lane] : -4;
+        const unsigned long long h0 = __ballot((e0 >> 2) == kk), h1 = __ballot((e1 >> 2) == kk);
+        if (h0) cls_kk = __builtin_amdgcn_readlane(e0, __builtin_ctzll(h0)) & 3;
+        else if (h1) cls_kk = __builtin_amdgcn_readlane(e1, __builtin_ctzll(h1)) & 3;
+    }
+    double q_kk = c.qc(cls_kk);
+    if (q_kk < 1.0 && u2 < q_kk) return kk;  // `smaller` and accepted (:278)
+    RunIter sm_{m - 1, K - 1, 1, 0, 0, 0}, lg_{m - 1, K - 1, 0, 0, 0, 0};
+    sm_.next(c);
+    lg_.next(c);
+    int J_kk = 0, c_i = 0;
+    bool carried = false, done = false;
+    double c_q = 0.0;
+    while (!done && lg_.r_cnt > 0 && (carried || sm_.r_cnt > 0)) {        // :259
+        const int large = lg_.r_top;                                    // larger.pop()
+        double ql = c.qc(lg_.r_cls);
+        lg_.take(c, 1);
+        for (;;) {
+            if (carried) {                                            // smaller.pop() is the large that dropped below 1
+                carried = false;
+                if (c_i == kk) { J_kk = large; q_kk = c_q; done = true; break; }
+                ql = ql + c_q;                                        // :264, left to right
+                ql = ql - 1.0;
+            } else {
+                if (sm_.r_cnt == 0) { if (large == kk) q_kk = ql; done = true; break; }   // `smaller` is dry
+                const double qs = c.qc(sm_.r_cls);
+                int n = sm_.r_cnt;                                      // smalls of this run popped before slot kk is
+                const bool hit = kk <= sm_.r_top && kk > sm_.r_top - n;
+                if (hit) n = sm_.r_top - kk;
+                int used = 0;
+                bool dem = false;
+                while (used < n) {                                    // the chain of one large over a run of equal smalls
+                    ql = ql + qs;
+                    ql = ql - 1.0;
+                    ++used;
+                    if (uni((int)(ql < 1.0))) { dem = true; break; }
+                }
+                sm_.take(c, used);
+                if (!dem) {
+                    if (hit) { J_kk = large; q_kk = qs; done = true; break; }   // :263 — the next small is slot kk
+                    continue;
+                }
+            }
+            if (uni((int)(ql < 1.0))) {                               // :265-266 — the large is the next small
+                if (lg_.r_cnt == 0) { if (large == kk) q_kk = ql; done = true; }  // nothing left to absorb it: J stays 0
+                else { carried = true; c_i = large; c_q = ql; }
+                break;
+            }
+        }
+    }
+    return (u2 < q_kk) ? kk : J_kk;                                   // :278-281
 }
 
 // Rows of at most 64 neighbours (84 % of the steps of a walk on a power-law graph, and nearly all whose slot kk is NOT

@@ -669,7 +669,7 @@ def test_directed_sinks_sharded_and_pass_bound(n2v):
 def test_budgeted_walk_lane_kernel_equals_table_walk(n2v, weighted, p, q):
     """Launches of >= ~2e5 walks of a partially stored engine run the lane-per-walk kernel (n2v_walk_otf.hip: stored steps
     per lane, rebuild steps served by the whole wave); smaller ones — every other budget test — the wave-per-walk one.
-    240k walks on the 20k-node hub graph at a third of the tables, Philox (64-B bursts, L = 16) and numpy stream (L = 13:
+    240k walks on the 20k-node hub graph at a third of the tables, Philox (16-B bursts, L = 16) and numpy stream (L = 13:
     single-id writes), against the fully stored tables."""
     import torch
     rs = np.random.RandomState(12)
