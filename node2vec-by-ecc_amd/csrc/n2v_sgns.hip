@@ -721,6 +721,18 @@ struct SpanSpec {                // n2v_sgns_train_span; dyn == NULL: an ordinar
     int64_t n_sub_total, n_local, shard_offset;
 };
 
+// CUs of the current device (MI355X: 256), asked once
+static int64_t n2v_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
 int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
                 float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
                 int32_t window, int32_t negative, const uint32_t* sample_int,
@@ -774,15 +786,24 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks * walk_splits + 3) / 4;
     // default grid: 256 CUs x 12 workgroups of 4 waves — every wave slot of the chip at this kernel's 36-40
-    // VGPRs (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096 8.0e8, 6144 8.3e8) — but never more than one
-    // wavefront per 64 vocabulary rows: the racing waves read each other's rows stale, and the link-prediction AUC
-    // moves away from the sequential algorithm's in proportion to waves in flight per row.  Measured against the
-    // sequential comparator on a 131 019-row hub graph (tests/probes/grid_band_probe.py, profiles/r03/logs): 3072
-    // workgroups -0.0022 (atomic) / -0.0013 (agent), 1024 -0.0005 / -0.0008, 512 -0.0002 / -0.0002, 256 +0.0001 /
-    // -0.0001 — at the SAME pair rate down to 256 (atomic: bound by the float-atomic rate) / 768 (agent) workgroups.
-    // C3 (10^6 rows) keeps its 3072.
+    // VGPRs (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096 8.0e8, 6144 8.3e8) — but
+    //  (1) never more than one wavefront per 64 vocabulary rows (per 128 with atomic rows, whose pair rate is bound by the
+    //      float-atomic rate and does not drop down to 256 workgroups): the racing waves read each other's rows stale, and
+    //      the link-prediction AUC moves away from the sequential algorithm's in proportion to waves in flight per row.
+    //      Against the sequential comparator (tests/probes/grid_band_probe.py, profiles/r03/logs), 131 019-row hub graph:
+    //      3072 workgroups -0.0022 (atomic) / -0.0013 (agent), 1024 -0.0005 / -0.0008, 512 -0.0002 / -0.0002, 256 +0.0001 /
+    //      -0.0001; 399 846 rows: 3072 -0.0023 / -0.0001, 1536 -0.0016 / -0.0005, 768 -0.0006 / -0.0002;
+    //  (2) a whole number of workgroups per CU once there is more than one: with 6 workgroups on most CUs and 7 on a few,
+    //      the waves of the fuller CUs fall behind, the pass takes 26 % longer and the AUC drops by 0.004 (399 846 rows:
+    //      grids 1560 / 1561 / 1562 / 1600 -0.0041 ... -0.0042 in 4.35 s, 1536 -0.0005 in 3.44 s —
+    //      tests/probes/grid_resonance_probe.py).  C3 (10^6 rows) keeps its 3072 = 12 x 256.
     int64_t cap = max_blocks > 0 ? max_blocks : 3072;
-    if (max_blocks <= 0 && cap > n_words / 256) cap = n_words / 256 > 16 ? n_words / 256 : 16;
+    if (max_blocks <= 0) {
+        const int64_t cus = n2v_cu_count();
+        if (cap > n_words / 256) cap = n_words / 256 > 16 ? n_words / 256 : 16;
+        if (update_mode == kAtomic && cap >= 2 * cus) cap /= 2;
+        if (cap > cus) cap -= cap % cus;
+    }
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);
 #define N2V_SGNS_LAUNCH_M(V, M)                                                            \
