@@ -52,6 +52,7 @@ struct OtfArgs {
     int32_t* status;
     // draw before building (n2v_wave_table.h): 1 = after the weights and their sum, 2 = dyadic counting first
     int32_t draw_first;
+    int32_t exact_sum;        // draw_first 2: 1/p and 1/q dyadic — the weights' sum is a count
     double wp, wq;            // 1/p, 1/q
 };
 
@@ -93,7 +94,7 @@ struct OtfWave {
         }
         int pk = kk;
         if (K <= 64 && a.draw_first) {                                // the table in registers, one slot per lane
-            pk = n2v::wave_draw_le64(a.g, ws, prev, base, nb0, K, kk, u2, a.draw_first == 2, a.wp, a.wq, lane);
+            pk = n2v::wave_draw_le64(a.g, ws, prev, base, nb0, K, kk, u2, a.draw_first == 2 && a.exact_sum, a.wp, a.wq, lane);
 #ifdef N2V_OTF_LAB_ALWAYS_ACCEPT   /* timing ceiling of the fast path only: WRONG walks */
             pk = pk < 0 ? pk : kk;
 #endif
@@ -101,8 +102,8 @@ struct OtfWave {
         } else {
             bool drawn = false;
             if (a.draw_first == 2) {         // dyadic weights: the pick from counts and a sweep over the three weight classes
-                const int d = n2v::dyadic_draw(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, reinterpret_cast<int32_t*>(Tl),
-                                               kLdsSlots * 4, reinterpret_cast<int32_t*>(ws.feed), lane);
+                const int d = n2v::dyadic_draw(a.g, ws, prev, base, K, kk, u2, a.wp, a.wq, a.exact_sum != 0,
+                                               reinterpret_cast<int32_t*>(Tl), kLdsSlots * 4, reinterpret_cast<int32_t*>(ws.feed), lane);
                 if (d >= 0) { pk = d; drawn = true; }   // -2: more common neighbours than the sweep's list holds -> build
             }
 #ifdef N2V_OTF_LAB_ALWAYS_ACCEPT
@@ -356,15 +357,17 @@ int launch_otf(const char* who, bool hybrid, const int64_t* row_ptr, const int32
         if (fit < 1) return n2v::fail(N2V_ERR_INVALID, "%s: scratch smaller than 4 x max_degree slots", who);
         if (blocks > fit) blocks = fit;
     }
-    // dyadic counting (n2v_wave_table.h): unweighted, undirected, 1/p and 1/q multiples of 2^-20 up to 2^10, degrees < 2^21
+    // three weight classes (n2v_wave_table.h): unweighted, undirected — 2; their sum a count: 1/p and 1/q multiples of
+    // 2^-20 up to 2^10, degrees < 2^21
     const double wp = 1.0 / p, wq = 1.0 / q;
     auto dyadic = [](double x) { return x > 0.0 && x <= 1024.0 && x * 1048576.0 == (double)(int64_t)(x * 1048576.0); };
-    int32_t draw_first = (!w && symmetric && dyadic(wp) && dyadic(wq) && max_degree < (1 << 21)) ? 2 : 1;
+    int32_t draw_first = (!w && symmetric) ? 2 : 1;
+    const int32_t exact_sum = dyadic(wp) && dyadic(wq) && max_degree < (1 << 21);
 #ifdef N2V_OTF_LAB_DRAW_FIRST   /* tools/lab/otf_variants.sh: 0 = always build the table, 1 = never count */
     draw_first = N2V_OTF_LAB_DRAW_FIRST < draw_first ? N2V_OTF_LAB_DRAW_FIRST : draw_first;
 #endif
     OtfArgs a{n2v::RowCtx{row_ptr, col, w, p, q, symmetric}, starts, n_starts, pos_begin, pos_count, round_begin, n_local, walk_length,
-              rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, node_fat, fat, recs, walks, lens, status, draw_first, wp, wq};
+              rng_mode, uniforms, walk_uoff, seed, scratch, max_degree, node_fat, fat, recs, walks, lens, status, draw_first, exact_sum, wp, wq};
     hipStream_t st = (hipStream_t)stream;
     // budgeted walk: one lane per walk once the launch is large enough to fill half the lanes of the resident waves
     if (hybrid && n_local >= blocks * 128) {

@@ -347,16 +347,7 @@ __device__ __forceinline__ void wave_finish_table(Slot* T, int K, double norm, i
 // below 2^32 — exact in fp64 — so the sum does not depend on the order and equals
 //     [prev in row(cur)] * 1/p  +  n_adj * 1  +  (K - [prev in row(cur)] - n_adj) * 1/q,     each product and sum exact,
 // with n_adj = |{x in row(cur): x != prev, x in row(prev)}| (has_edge(x, prev) on an undirected graph, :145).  The count
-// walks the SHORTER of the two sorted rows and searches the longer one; no table, no LDS, no serial chain.
-__device__ __forceinline__ bool sorted_contains(const int32_t* __restrict__ row, int n, int32_t v) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (row[mid] < v) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo < n && row[lo] == v;
-}
+// walks the SHORTER of the two sorted rows and searches the longer one (dyadic_draw below); no serial chain.
 // A long sorted row searched by the lanes of one wave.  Binary searches in global memory are log2(n) DEPENDENT loads each
 // (a hub row of thousands: ~8 us); here the row is first copied into `big` (LDS, `cap` ints) with pipelined coalesced
 // loads when it fits, else every stride-th element is (pivots): a search is LDS probes plus at most log2(stride)
@@ -443,8 +434,12 @@ struct RunIter {
         if (r_cnt == 0) next(c);
     }
 };
+// exact_sum false (1/p or 1/q not dyadic; still an unweighted undirected graph, still three weight classes): the sum is
+// the reference's left-to-right chain (:149), run by run — a gap of n far slots is n times `norm = norm + 1/q` in
+// registers — instead of the count formula; everything else is the same.
 __device__ __forceinline__ int dyadic_draw(const RowCtx& a, const WaveScratch& ws, int32_t prev, int64_t base, int K, int kk,
-                                           double u2, double wp, double wq, int32_t* big, int cap, int32_t* spec, int lane) {
+                                           double u2, double wp, double wq, bool exact_sum, int32_t* big, int cap, int32_t* spec,
+                                           int lane) {
     if (prev < 0) {                          // first step: the node table, all weights 1 (:184-188): one class, no pairing
         const double q = (double)K * (1.0 / (double)K);
         return (u2 < q) ? kk : 0;
@@ -506,7 +501,21 @@ __device__ __forceinline__ int dyadic_draw(const RowCtx& a, const WaveScratch& w
         if (n_prev && lane == 0) spec[before] = p_idx * 4 + 2;
         wave_sync();
     }
-    const double norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;   // exact (see above)
+    double norm;
+    if (exact_sum) {
+        norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;   // exact (see above)
+    } else {                                 // :149, left to right over the runs
+        norm = 0.0;
+        int pos = 0;
+        for (int j = 0; j <= m; ++j) {
+            const int e = j < m ? uni(spec[j]) : K * 4;
+            for (int g = (e >> 2) - pos; g > 0; --g) norm = norm + wq;
+            if (j < m) norm = norm + ((e & 3) == 2 ? wp : 1.0);
+            pos = (e >> 2) + 1;
+        }
+        norm = unid(norm);
+    }
+    if (norm == 0.0) return -2;              // (negative p or q) the table builder reports it (:150)
     const double Kd = (double)K;
     const double q0 = Kd * (wq / norm), q1 = Kd * (1.0 / norm), q2 = Kd * (wp / norm);
     const ClassSweep c{spec, m, (q0 < 1.0 ? 1 : 0) | (q1 < 1.0 ? 2 : 0) | (q2 < 1.0 ? 4 : 0),
@@ -575,7 +584,7 @@ __device__ __forceinline__ int dyadic_draw(const RowCtx& a, const WaveScratch& w
 // picks (:277-281) or -1 when the weights sum to 0 (:150, ZeroDivisionError).
 //   exact_sum: every partial sum is exact (dyadic weights, see above) — the butterfly sum equals the left-to-right one.
 //   nb: the lane's neighbour col[base + lane] (lanes < K), already loaded by the caller.
-//   wp, wq: 1/p, 1/q (used when exact_sum: the weight classes are lane masks and the sum is a count, as in dyadic_accepts).
+//   wp, wq: 1/p, 1/q (used when exact_sum: the weight classes are lane masks and the sum is a count, as in dyadic_draw).
 // Slot kk is tested BEFORE the other lanes normalise (one fp64 division instead of 64 lanes' worth of them).
 __device__ __forceinline__ int wave_draw_le64(const RowCtx& a, const WaveScratch& ws, int32_t src, int64_t base, int32_t nb, int K,
                                               int kk, double u2, bool exact_sum, double wp, double wq, int lane) {
@@ -589,7 +598,7 @@ __device__ __forceinline__ int wave_draw_le64(const RowCtx& a, const WaveScratch
         if (src < 0) { norm = (double)K; w_kk = 1.0; w = 1.0; }      // the node table: all weights 1 (:184-188)
         else {
             const int n_prev = __popcll(mp), n_adj = __popcll(ma);
-            norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;   // exact, see dyadic_accepts
+            norm = ((double)n_prev * wp + (double)n_adj) + (double)(K - n_prev - n_adj) * wq;   // exact, see dyadic_draw
             w_kk = ((mp >> kk) & 1ULL) ? wp : (((ma >> kk) & 1ULL) ? 1.0 : wq);
             w = isp ? wp : (adj ? 1.0 : wq);
         }
