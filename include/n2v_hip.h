@@ -275,7 +275,8 @@ int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bi
  *   N2V_SGNS_ATOMIC agent-scope loads + float atomic adds (no update is lost).
  * max_blocks <= 0 picks the default grid: 3072 workgroups of 4 wavefronts (every wave slot), at most one wavefront per 64
  * vocabulary rows (per 128 with atomic rows on large tables), and a whole number of workgroups per CU once there is more
- * than one — the acceptance band (AUC within +-0.002 of the sequential algorithm) was measured to need both. */
+ * than one — the acceptance band (AUC within +-0.002 of the sequential algorithm) was measured to need both
+ * (n2v_sgns_default_blocks reports that grid). */
 #define N2V_SGNS_PLAIN 0
 #define N2V_SGNS_AGENT 1
 #define N2V_SGNS_ATOMIC 2
@@ -311,6 +312,9 @@ int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, int64_t n_loc
                         uint64_t seed, unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
                         int32_t walk_splits, const int64_t* interval_state, int32_t sub_index,
                         int32_t subs_per_interval, int64_t n_sub_total, int64_t shard_offset, void* stream);
+
+/* Workgroups of the default SGNS grid (max_blocks <= 0) for a vocabulary of n_words rows and a row mode. */
+int32_t n2v_sgns_default_blocks(int64_t n_words, int32_t update_mode);
 
 /* ---- replica merges of the multi-GPU trainer (no counterpart in the reference, whose gensim
  * threads share one table: src/main.py:87 `workers=`) ------------------------------------------------------

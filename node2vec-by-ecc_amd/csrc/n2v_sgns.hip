@@ -733,6 +733,16 @@ static int64_t n2v_cu_count() {
     return cus;
 }
 
+// the default grid's workgroup count (rules (1) and (2) in sgns_launch)
+static int64_t default_grid(int64_t n_words, int32_t update_mode) {
+    const int64_t cus = n2v_cu_count();
+    int64_t cap = 3072;
+    if (cap > n_words / 256) cap = n_words / 256 > 16 ? n_words / 256 : 16;
+    if (update_mode == kAtomic && cap >= 2 * cus) cap /= 2;
+    if (cap > cus) cap -= cap % cus;
+    return cap;
+}
+
 int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int64_t n_walks, int32_t walk_stride,
                 float* syn0, float* syn1neg, int64_t n_words, int32_t dim, int32_t row_stride,
                 int32_t window, int32_t negative, const uint32_t* sample_int,
@@ -797,13 +807,7 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     //      the waves of the fuller CUs fall behind, the pass takes 26 % longer and the AUC drops by 0.004 (399 846 rows:
     //      grids 1560 / 1561 / 1562 / 1600 -0.0041 ... -0.0042 in 4.35 s, 1536 -0.0005 in 3.44 s —
     //      tests/probes/grid_resonance_probe.py).  C3 (10^6 rows) keeps its 3072 = 12 x 256.
-    int64_t cap = max_blocks > 0 ? max_blocks : 3072;
-    if (max_blocks <= 0) {
-        const int64_t cus = n2v_cu_count();
-        if (cap > n_words / 256) cap = n_words / 256 > 16 ? n_words / 256 : 16;
-        if (update_mode == kAtomic && cap >= 2 * cus) cap /= 2;
-        if (cap > cus) cap -= cap % cus;
-    }
+    const int64_t cap = max_blocks > 0 ? max_blocks : default_grid(n_words, update_mode);
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);
 #define N2V_SGNS_LAUNCH_M(V, M)                                                            \
@@ -859,4 +863,8 @@ extern "C" int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, in
                        negative, sample_int, cum_table, lut, lut_bits, alpha, min_alpha, 0, sentences_step, sentences_total,
                        alpha_batch, seed, 0, pair_count, update_mode, max_blocks, walk_splits,
                        SpanSpec{interval_state, sub_index, subs_per_interval, n_sub_total, n_local, shard_offset}, stream);
+}
+
+extern "C" int32_t n2v_sgns_default_blocks(int64_t n_words, int32_t update_mode) {
+    return (int32_t)default_grid(n_words < 0 ? 0 : n_words, update_mode & 3);
 }

@@ -446,3 +446,20 @@ def test_out_of_band_modes_are_fenced():
     import main as n2v_main
     assert n2v_main.parse_args(["--input", "x"]).allow_out_of_band is False
     assert n2v_main.parse_args(["--input", "x", "--allow-out-of-band", "--merge", "hot"]).allow_out_of_band is True
+
+
+def test_default_grid_is_whole_workgroups_per_cu():
+    """n2v_sgns_train's default grid (include/n2v_hip.h): at most one wavefront per 64 vocabulary rows (128 with atomic
+    rows on large tables), never more than 3 072 workgroups, and a whole number of workgroups per CU once there is
+    more than one — 1 561 workgroups on a 399 846-row table cost 0.004 of AUC."""
+    from n2v_hip import _lib
+    lib = _lib.load()
+    cus = 256                                            # without a GPU the library assumes MI355X's 256 CUs
+    for n in (10, 3000, 19998, 65535, 131019, 131072, 200000, 399846, 600000, 10**6, 10**8):
+        for mode, rows_per_wave in ((_lib.N2V_SGNS_AGENT if hasattr(_lib, "N2V_SGNS_AGENT") else 1, 64), (2, 64)):
+            b = lib.n2v_sgns_default_blocks(n, mode)
+            assert 16 <= b <= 3072
+            assert b <= max(16, n // 256)
+            assert b <= cus or b % cus == 0, (n, mode, b)
+    assert lib.n2v_sgns_default_blocks(399846, 1) == 1536 and lib.n2v_sgns_default_blocks(399846, 2) == 768
+    assert lib.n2v_sgns_default_blocks(10**6, 1) == 3072
