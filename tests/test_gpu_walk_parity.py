@@ -699,6 +699,37 @@ def test_budgeted_walk_lane_kernel_equals_table_walk(n2v, weighted, p, q):
     assert torch.equal(a2.lens, b2.lens) and torch.equal(a2.walks, b2.walks)
 
 
+@pytest.mark.parametrize("commons", [70, 126, 127, 128, 129, 300])
+@pytest.mark.parametrize("p,q", [(0.25, 4.0), (0.3, 0.7)])
+def test_on_the_fly_with_many_common_neighbours(n2v, commons, p, q):
+    """Two hubs joined by an edge and sharing `commons` neighbours (plus private leaves): the class sweep of the
+    on-the-fly walk keeps the positions of the weight-1 slots in a 128-entry list (prev's slot included) and hands rows
+    with more of them to the table builder — both sides of that limit, dyadic and non-dyadic p, q, against the stored
+    tables."""
+    import torch
+    from n2v_hip import csr
+    src, dst = [0], [1]
+    for c in range(2, 2 + commons):
+        src += [0, 1]
+        dst += [c, c]
+    nxt = 2 + commons
+    for hub, leaves in ((0, 90), (1, 150)):
+        for _ in range(leaves):
+            src.append(hub)
+            dst.append(nxt)
+            nxt += 1
+    for c in range(2, 2 + commons, 3):                      # a few commons know each other: rows of <= 64 with adjacency
+        src.append(c)
+        dst.append(2 + (c - 2 + 1) % commons)
+    cg = csr.from_edges(np.array(src), np.array(dst), None, False)
+    g = n2v.Graph.from_csr(cg, p, q, rng="philox", seed=3)
+    g.preprocess_transition_probs()
+    a = g.simulate_walks(40, 12)
+    g.force_on_the_fly = True
+    b = g.simulate_walks_on_the_fly(40, 12)
+    assert torch.equal(a.lens, b.lens) and torch.equal(a.walks, b.walks)
+
+
 def test_randomised_parity_sweep(n2v):
     """40 random small graphs (directed or not, weighted or not, self-loops, isolated targets,
     duplicate lines, p and q from a grid incl. 1): tables and reference-exact walks vs the C oracle
