@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define N2V_ABI_VERSION 1
+#define N2V_ABI_VERSION 2
 
 #define N2V_OK 0
 #define N2V_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, limit exceeded) */
@@ -276,7 +276,12 @@ int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bi
  * max_blocks <= 0 picks the default grid: 3072 workgroups of 4 wavefronts (every wave slot), at most one wavefront per 64
  * vocabulary rows (per 128 with atomic rows on large tables), and a whole number of workgroups per CU once there is more
  * than one — the acceptance band (AUC within +-0.002 of the sequential algorithm) was measured to need both
- * (n2v_sgns_default_blocks reports that grid). */
+ * (n2v_sgns_default_blocks reports that grid).
+ * work_counter: device uint64[1] owned by the caller (one per model; the launch resets it in stream order): sentences are
+ * handed to the wavefronts IN ORDER through it, which keeps all waves inside one moving window of the corpus — the
+ * sequential algorithm's processing order up to the width of that window.  With atomic rows the link-prediction AUC then
+ * equals the sequential comparator's to 3e-5 at any grid (400k-node fixture; static stride: -0.0023 at 3072 workgroups).
+ * NULL: static grid stride (wave w trains sentences w, w + n_waves, ...), kept for comparison. */
 #define N2V_SGNS_PLAIN 0
 #define N2V_SGNS_AGENT 1
 #define N2V_SGNS_ATOMIC 2
@@ -294,7 +299,7 @@ int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t n_walks, i
                    float min_alpha, int64_t sentences_base, int64_t sentences_step,
                    int64_t sentences_total, int64_t alpha_batch, uint64_t seed, uint64_t walk_id_base,
                    unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
-                   int32_t walk_splits, void* stream);
+                   int32_t walk_splits, unsigned long long* work_counter, void* stream);
 
 /* The same launch with its walk range read from DEVICE memory, so that a captured launch (hipGraph) can be replayed for
  * every merge interval of a pass (the tiered merges issue ~15 000 short launches per pass at 8 GPUs; replayed from a
@@ -311,7 +316,8 @@ int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, int64_t n_loc
                         float min_alpha, int64_t sentences_step, int64_t sentences_total, int64_t alpha_batch,
                         uint64_t seed, unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
                         int32_t walk_splits, const int64_t* interval_state, int32_t sub_index,
-                        int32_t subs_per_interval, int64_t n_sub_total, int64_t shard_offset, void* stream);
+                        int32_t subs_per_interval, int64_t n_sub_total, int64_t shard_offset,
+                        unsigned long long* work_counter, void* stream);
 
 /* Workgroups of the default SGNS grid (max_blocks <= 0) for a vocabulary of n_words rows and a row mode. */
 int32_t n2v_sgns_default_blocks(int64_t n_words, int32_t update_mode);

@@ -55,6 +55,7 @@ struct SgnsArgs {
     int64_t sent_base, sent_step, sent_total, alpha_batch;
     uint64_t seed, walk_id_base;
     unsigned long long* pair_count;
+    unsigned long long* work;    // NULL: static grid stride; else the in-order item counter (reset by the launch)
     int32_t lpad;
     int32_t splits;   // wavefronts per walk (>= 1): split s trains the centres [s*n/S, (s+1)*n/S) of the sentence
     int32_t predraw;  // 1: all negatives of a centre are drawn by the lanes in parallel before its pairs (short launches)
@@ -258,6 +259,17 @@ __device__ __forceinline__ void add_row(float* base, int64_t row, int stride, in
 }
 
 // G = target slots in use per group of 8 (6 when negative == 5: the centre + 5 draws)
+// Sentences (items) are handed to the wavefronts IN ORDER by a device counter: every wave then works inside one narrow,
+// moving window of the corpus, like the threads of the sequential algorithm's job queue.  With the static grid stride
+// (item = wave, wave + n_waves, ...) the waves drift apart — a wave on a fuller CU falls behind by whole percents of the
+// corpus — and the link-prediction AUC moved away from the sequential comparator with the grid (399 846
+// rows, lossless rows: -0.0023 at 3072 workgroups, -0.0035 at 1561; in order: -0.00003 at every grid).
+__device__ __forceinline__ int64_t next_item(unsigned long long* counter, int lane) {
+    unsigned long long v = 0;
+    if (lane == 0) v = atomicAdd(counter, 1ull);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
 template <int VPL, int G, int MODE>
 __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a_in) {
     SgnsArgs a = a_in;
@@ -278,7 +290,8 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a_in) {
     // one between sentences.  That is what lets a launch of a few hundred walks fill the chip (tiered merges).
     const int S = a.splits;
     const int64_t n_items = a.n_walks * S;
-    for (int64_t item = (int64_t)blockIdx.x * 4 + wv; item < n_items; item += n_waves) {
+    for (int64_t item = a.work ? next_item(a.work, lane) : (int64_t)blockIdx.x * 4 + wv; item < n_items;
+         item = a.work ? next_item(a.work, lane) : item + n_waves) {
         const int64_t wi = S == 1 ? item : item / S;
         const int sp = S == 1 ? 0 : (int)(item - wi * S);
         const int len = a.lens ? a.lens[wi] : a.walk_stride;
@@ -750,7 +763,8 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
                 float min_alpha, int64_t sentences_base, int64_t sentences_step,
                 int64_t sentences_total, int64_t alpha_batch,
                 uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
-                int32_t update_mode, int32_t max_blocks, int32_t walk_splits, const SpanSpec& span, void* stream) {
+                int32_t update_mode, int32_t max_blocks, int32_t walk_splits, const SpanSpec& span,
+                unsigned long long* work_counter, void* stream) {
     if (walk_splits < 1 || walk_splits > walk_stride)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_splits %d outside [1, %d]", (int)walk_splits, (int)walk_stride);
     if (n_walks < 0 || walk_stride < 1 || n_words < 1 || dim < 1 || window < 1 || negative < 0 || negative > 64)
@@ -784,6 +798,7 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     a.window = window; a.negative = negative; a.sample_int = sample_int;
     a.cum_table = cum_table; a.lut = lut; a.lut_shift = 31 - lut_bits;
     a.alpha0 = alpha; a.min_alpha = min_alpha;
+    a.work = share ? nullptr : work_counter;   // (the shared-negatives kernel keeps the static stride)
     a.sent_base = sentences_base; a.sent_step = sentences_step; a.sent_total = sentences_total;
     a.alpha_batch = alpha_batch;
     a.seed = seed; a.walk_id_base = walk_id_base; a.pair_count = pair_count;
@@ -810,6 +825,8 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     const int64_t cap = max_blocks > 0 ? max_blocks : default_grid(n_words, update_mode);
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);
+    if (a.work && hipMemsetAsync(a.work, 0, sizeof(unsigned long long), st) != hipSuccess)
+        return n2v::fail(N2V_ERR_HIP, "%s: resetting the work counter failed", who);
 #define N2V_SGNS_LAUNCH_M(V, M)                                                            \
     if (share) hipLaunchKernelGGL((sgns_shared_kernel<V, M>), grid, block, shmem, st, a);     \
     else if (negative <= 5) hipLaunchKernelGGL((sgns_kernel<V, 6, M>), grid, block, shmem, st, a); \
@@ -837,11 +854,12 @@ extern "C" int n2v_sgns_train(const int32_t* walks, const int32_t* lens, int64_t
                               float min_alpha, int64_t sentences_base, int64_t sentences_step,
                               int64_t sentences_total, int64_t alpha_batch,
                               uint64_t seed, uint64_t walk_id_base, unsigned long long* pair_count,
-                              int32_t update_mode, int32_t max_blocks, int32_t walk_splits, void* stream) {
+                              int32_t update_mode, int32_t max_blocks, int32_t walk_splits,
+                              unsigned long long* work_counter, void* stream) {
     return sgns_launch("n2v_sgns_train", walks, lens, n_walks, walk_stride, syn0, syn1neg, n_words, dim, row_stride, window,
                        negative, sample_int, cum_table, lut, lut_bits, alpha, min_alpha, sentences_base, sentences_step,
                        sentences_total, alpha_batch, seed, walk_id_base, pair_count, update_mode, max_blocks, walk_splits,
-                       SpanSpec{nullptr, 0, 1, 1, 0, 0}, stream);
+                       SpanSpec{nullptr, 0, 1, 1, 0, 0}, work_counter, stream);
 }
 
 extern "C" int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, int64_t n_local, int32_t walk_stride,
@@ -851,7 +869,8 @@ extern "C" int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, in
                                    float min_alpha, int64_t sentences_step, int64_t sentences_total, int64_t alpha_batch,
                                    uint64_t seed, unsigned long long* pair_count, int32_t update_mode, int32_t max_blocks,
                                    int32_t walk_splits, const int64_t* interval_state, int32_t sub_index,
-                                   int32_t subs_per_interval, int64_t n_sub_total, int64_t shard_offset, void* stream) {
+                                   int32_t subs_per_interval, int64_t n_sub_total, int64_t shard_offset,
+                                   unsigned long long* work_counter, void* stream) {
     if (!interval_state || subs_per_interval < 1 || sub_index < 0 || sub_index >= subs_per_interval || n_sub_total < subs_per_interval ||
         (n_sub_total % subs_per_interval) != 0 || n_local < 0 || shard_offset < 0)
         return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train_span: bad span (sub %d of %d, %lld sub-intervals, %lld walks)",
@@ -862,7 +881,7 @@ extern "C" int n2v_sgns_train_span(const int32_t* walks, const int32_t* lens, in
     return sgns_launch("n2v_sgns_train_span", walks, lens, max_walks, walk_stride, syn0, syn1neg, n_words, dim, row_stride, window,
                        negative, sample_int, cum_table, lut, lut_bits, alpha, min_alpha, 0, sentences_step, sentences_total,
                        alpha_batch, seed, 0, pair_count, update_mode, max_blocks, walk_splits,
-                       SpanSpec{interval_state, sub_index, subs_per_interval, n_sub_total, n_local, shard_offset}, stream);
+                       SpanSpec{interval_state, sub_index, subs_per_interval, n_sub_total, n_local, shard_offset}, work_counter, stream);
 }
 
 extern "C" int32_t n2v_sgns_default_blocks(int64_t n_words, int32_t update_mode) {

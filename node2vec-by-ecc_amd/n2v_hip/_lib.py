@@ -55,10 +55,10 @@ SIGNATURES = {
     "n2v_build_neg_lut": (C.c_int, [_ptr, _i64, _i32, _ptr, _ptr]),
     "n2v_sgns_train": (C.c_int, [_ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _ptr, _ptr,
                                  _ptr, _i32, C.c_float, C.c_float, _i64, _i64, _i64, _i64, _u64, _u64, _ptr, _i32,
-                                 _i32, _i32, _ptr]),
+                                 _i32, _i32, _ptr, _ptr]),
     "n2v_sgns_train_span": (C.c_int, [_ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _ptr, _ptr,
                                       _ptr, _i32, C.c_float, C.c_float, _i64, _i64, _i64, _u64, _ptr, _i32, _i32, _i32,
-                                      _ptr, _i32, _i32, _i64, _i64, _ptr]),
+                                      _ptr, _i32, _i32, _i64, _i64, _ptr, _ptr]),
     "n2v_sgns_default_blocks": (C.c_int32, [_i64, _i32]),
     "n2v_merge_snapshot": (C.c_int, [_ptr, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "n2v_merge_hot_apply": (C.c_int, [_ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i64, _ptr, _i32, _ptr]),

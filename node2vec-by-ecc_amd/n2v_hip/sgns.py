@@ -160,6 +160,8 @@ class SgnsModel:
         self.syn0 = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
         self.syn1neg = torch.empty((self.n_words, self.stride), dtype=torch.float32, device=d)
         self.pair_count = torch.zeros(1, dtype=torch.int64, device=d)
+        # in-order hand-out of the sentences to the wavefronts (n2v_sgns_train's work_counter); None: static grid stride
+        self.work_counter = torch.zeros(1, dtype=torch.int64, device=d)
         self.counts = None
         self.sample_int = self.cum_table = self.lut = None
         self.reset_weights()
@@ -219,7 +221,8 @@ class SgnsModel:
             _lib.ptr(self.cum_table), _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha,
             int(sentences_base), int(sentences_step), int(sentences_total), max(1, MAX_WORDS_IN_BATCH // L),
             self.seed & (2**64 - 1),
-            int(walk_id_base), _lib.ptr(self.pair_count), mode, int(max_blocks), int(splits), stream))
+            int(walk_id_base), _lib.ptr(self.pair_count), mode, int(max_blocks), int(splits),
+            _lib.ptr(self.work_counter), stream))
 
     def span_trainer(self, walks, lens, sentences_total, sentences_step, splits="auto"):
         """-> launch(b, e, sentences_base, walk_id_base): train_pass over walks[b:e] without building tensor views —
@@ -260,7 +263,7 @@ class SgnsModel:
                 _lib.ptr(self.lut), LUT_BITS, self.alpha, self.min_alpha, int(sentences_step), int(sentences_total),
                 max(1, MAX_WORDS_IN_BATCH // L), self.seed & (2**64 - 1), _lib.ptr(self.pair_count), mode, 0, int(splits),
                 _lib.ptr(interval_state), int(sub_index), int(subs_per_interval), int(n_sub_total), int(shard_offset),
-                _lib.stream_ptr(dev)))
+                _lib.ptr(self.work_counter), _lib.stream_ptr(dev)))
         return launch
 
     def pairs_trained(self):
