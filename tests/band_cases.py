@@ -77,6 +77,12 @@ CASES = {
 }
 
 
+# graphs of probes only (no comparator fixture: the sequential comparator would need ~10 h of one core)
+PROBE_CASES = {
+    "hub1m_10x80": ("hub", dict(n=1000000, k=5000, m_in=10000000, m_out=2000000, seed=4), 10, 80),   # C3's size
+}
+
+
 def sha16(arr):
     return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()[:16]
 
@@ -87,7 +93,7 @@ def build(name):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "node2vec-by-ecc_amd"))
     from n2v_hip import csr, linkpred
-    kind, kw, rounds, L = CASES[name]
+    kind, kw, rounds, L = (CASES.get(name) or PROBE_CASES[name])
     edges = (planted_partition if kind == "planted" else hub_partition)(**kw)
     tr, te = linkpred.split_edges(edges)
     full = csr.from_edges(edges[:, 0], edges[:, 1], None, False)
