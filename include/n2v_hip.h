@@ -271,7 +271,8 @@ int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bi
  * pair_count (may be NULL): incremented by the number of (centre, context) pairs trained.
  * update_mode: how the racing wavefronts share rows (gensim's workers race the same way):
  *   N2V_SGNS_PLAIN  plain loads/stores (per-XCD L2 copies; fastest, loses updates),
- *   N2V_SGNS_AGENT  agent-scope loads and stores (one copy at the memory side),
+ *   N2V_SGNS_AGENT  agent-scope loads and stores (one copy at the memory side); the centre word's row, held for a
+ *                   whole window, gets its accumulated change ADDED (float atomics) instead of being written back whole,
  *   N2V_SGNS_ATOMIC agent-scope loads + float atomic adds (no update is lost).
  * max_blocks <= 0 picks the default grid: 3072 workgroups of 4 wavefronts (every wave slot), at most one wavefront per 64
  * vocabulary rows (per 128 with atomic rows on large tables), and a whole number of workgroups per CU once there is more

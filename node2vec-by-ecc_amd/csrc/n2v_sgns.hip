@@ -258,6 +258,22 @@ __device__ __forceinline__ void add_row(float* base, int64_t row, int stride, in
         __hip_atomic_fetch_add(q + i * 64, d.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// row += delta in load_row<VPL, kAgent>'s lane layout (the lane's own floats): the centre row of kAgent, see sgns_kernel
+template <int VPL>
+__device__ __forceinline__ void add_row_packed(float* base, int64_t row, int stride, int lane, const Row<VPL>& d) {
+    float* p = base + row * stride + lane_off<VPL>(lane);
+    if constexpr (VPL <= 2) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) __hip_atomic_fetch_add(p + v, d.v[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; i += 4)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                __hip_atomic_fetch_add(p + i * 64 + v, d.v[i + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // G = target slots in use per group of 8 (6 when negative == 5: the centre + 5 draws)
 // Sentences (items) are handed to the wavefronts IN ORDER by a device counter: every wave then works inside one narrow,
 // moving window of the corpus, like the threads of the sequential algorithm's job queue.  With the static grid stride
@@ -473,7 +489,12 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a_in) {
                 ++pidx;
                 ++pairs_done;
             }
+            // The centre row sits in registers for the whole window (~20 pairs, tens of microseconds): written back whole it
+            // would erase every update other waves made to it meanwhile — by far the longest exposure of any row.  kAgent
+            // therefore ADDS this wave's accumulated change, like kAtomic (one atomic row per centre: < 1 % of the row
+            // updates); the context and negative rows, held for one pair, keep their whole-row stores.
             if constexpr (MODE == kAtomic) add_row<VPL>(a.syn1neg, ci, a.row_stride, lane, cd);
+            else if constexpr (MODE == kAgent) add_row_packed<VPL>(a.syn1neg, ci, a.row_stride, lane, cd);
             else store_row<VPL, MODE>(a.syn1neg, ci, a.row_stride, lane, c);
         }
         __builtin_amdgcn_wave_barrier();  // LDS sentence is reused by the next walk
