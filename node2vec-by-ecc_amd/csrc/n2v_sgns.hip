@@ -481,6 +481,10 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a_in) {
                 }
                 if constexpr (MODE == kAtomic) {
                     add_row<VPL>(a.syn0, xj, a.row_stride, lane, work);
+#ifdef N2V_SGNS_LAB_CONTEXT_ADD
+                } else if constexpr (MODE == kAgent) {
+                    add_row_packed<VPL>(a.syn0, xj, a.row_stride, lane, work);
+#endif
                 } else {
 #pragma unroll
                     for (int v = 0; v < VPL; ++v) h.v[v] += work.v[v];
@@ -614,6 +618,10 @@ __global__ void __launch_bounds__(256) sgns_shared_kernel(SgnsArgs a_in) {
                 }
                 if constexpr (MODE == kAtomic) {
                     add_row<VPL>(a.syn0, xj, a.row_stride, lane, work);
+#ifdef N2V_SGNS_LAB_CONTEXT_ADD
+                } else if constexpr (MODE == kAgent) {
+                    add_row_packed<VPL>(a.syn0, xj, a.row_stride, lane, work);
+#endif
                 } else {
 #pragma unroll
                     for (int v = 0; v < VPL; ++v) h.v[v] += work.v[v];
