@@ -275,7 +275,7 @@ int n2v_build_neg_lut(const uint32_t* cum_table, int64_t n_words, int32_t lut_bi
  *                   whole window, gets its accumulated change ADDED (float atomics) instead of being written back whole,
  *   N2V_SGNS_ATOMIC agent-scope loads + float atomic adds (no update is lost).
  * max_blocks <= 0 picks the default grid: 3072 workgroups of 4 wavefronts (every wave slot), at most one wavefront per 64
- * vocabulary rows (per 128 with atomic rows on large tables), and a whole number of workgroups per CU once there is more
+ * vocabulary rows, and a whole number of workgroups per CU once there is more
  * than one — the acceptance band (AUC within +-0.002 of the sequential algorithm) was measured to need both
  * (n2v_sgns_default_blocks reports that grid).
  * work_counter: device uint64[1] owned by the caller (one per model; the launch resets it in stream order): sentences are

@@ -306,6 +306,8 @@ __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a_in) {
     // one between sentences.  That is what lets a launch of a few hundred walks fill the chip (tiered merges).
     const int S = a.splits;
     const int64_t n_items = a.n_walks * S;
+    // (every item comes off the counter, the first one too: a workgroup that only becomes resident late in the pass must not
+    // start with the early sentence its index names — measured: -0.0037 at 3072 workgroups on the 400k fixture)
     for (int64_t item = a.work ? next_item(a.work, lane) : (int64_t)blockIdx.x * 4 + wv; item < n_items;
          item = a.work ? next_item(a.work, lane) : item + n_waves) {
         const int64_t wi = S == 1 ? item : item / S;
@@ -780,7 +782,6 @@ static int64_t default_grid(int64_t n_words, int32_t update_mode) {
     const int64_t cus = n2v_cu_count();
     int64_t cap = 3072;
     if (cap > n_words / 256) cap = n_words / 256 > 16 ? n_words / 256 : 16;
-    if (update_mode == kAtomic && cap >= 2 * cus) cap /= 2;
     if (cap > cus) cap -= cap % cus;
     return cap;
 }
@@ -839,10 +840,11 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     const size_t shmem = (size_t)4 * a.lpad * sizeof(int32_t);
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks * walk_splits + 3) / 4;
-    // default grid: 256 CUs x 12 workgroups of 4 waves — every wave slot of the chip at this kernel's 36-40
-    // VGPRs (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096 8.0e8, 6144 8.3e8) — but
-    //  (1) never more than one wavefront per 64 vocabulary rows (per 128 with atomic rows, whose pair rate is bound by the
-    //      float-atomic rate and does not drop down to 256 workgroups): the racing waves read each other's rows stale, and
+    // default grid: 256 CUs x 12 workgroups of 4 waves (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096
+    // 8.0e8, 6144 8.3e8; at today's 63 VGPRs 7 of the 12 are resident at a time and the others follow as slots free up —
+    // harmless with the in-order hand-out, and the reason the static stride lost the band at large grids: a workgroup
+    // that starts late trains its whole strided share of the corpus after everybody else) — but
+    //  (1) never more than one wavefront per 64 vocabulary rows: the racing waves read each other's rows stale, and
     //      the link-prediction AUC moves away from the sequential algorithm's in proportion to waves in flight per row.
     //      Against the sequential comparator (tests/probes/grid_band_probe.py, profiles/r03/logs), 131 019-row hub graph:
     //      3072 workgroups -0.0022 (atomic) / -0.0013 (agent), 1024 -0.0005 / -0.0008, 512 -0.0002 / -0.0002, 256 +0.0001 /
@@ -857,6 +859,9 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     const int64_t cap = max_blocks > 0 ? max_blocks : default_grid(n_words, update_mode);
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(256);
+    // a launch in which no wave gets a second item needs no hand-out (the replicas' short launches: thousands per pass,
+    // and 6 640 waves asking one address for "nothing left" cost 90 us each time)
+    if (n_walks * walk_splits <= blocks * 4) a.work = nullptr;
     if (a.work && hipMemsetAsync(a.work, 0, sizeof(unsigned long long), st) != hipSuccess)
         return n2v::fail(N2V_ERR_HIP, "%s: resetting the work counter failed", who);
 #define N2V_SGNS_LAUNCH_M(V, M)                                                            \

@@ -449,8 +449,7 @@ def test_out_of_band_modes_are_fenced():
 
 
 def test_default_grid_is_whole_workgroups_per_cu():
-    """n2v_sgns_train's default grid (include/n2v_hip.h): at most one wavefront per 64 vocabulary rows (128 with atomic
-    rows on large tables), never more than 3 072 workgroups, and a whole number of workgroups per CU once there is
+    """n2v_sgns_train's default grid (include/n2v_hip.h): at most one wavefront per 64 vocabulary rows, never more than 3 072 workgroups, and a whole number of workgroups per CU once there is
     more than one — 1 561 workgroups on a 399 846-row table cost 0.004 of AUC."""
     from n2v_hip import _lib
     lib = _lib.load()
@@ -461,5 +460,5 @@ def test_default_grid_is_whole_workgroups_per_cu():
             assert 16 <= b <= 3072
             assert b <= max(16, n // 256)
             assert b <= cus or b % cus == 0, (n, mode, b)
-    assert lib.n2v_sgns_default_blocks(399846, 1) == 1536 and lib.n2v_sgns_default_blocks(399846, 2) == 768
-    assert lib.n2v_sgns_default_blocks(10**6, 1) == 3072
+    assert lib.n2v_sgns_default_blocks(399846, 1) == 1536 and lib.n2v_sgns_default_blocks(399846, 2) == 1536
+    assert lib.n2v_sgns_default_blocks(10**6, 1) == 3072 and lib.n2v_sgns_default_blocks(10**6, 2) == 3072
