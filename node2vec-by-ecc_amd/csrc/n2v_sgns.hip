@@ -782,6 +782,9 @@ static int64_t default_grid(int64_t n_words, int32_t update_mode) {
     const int64_t cus = n2v_cu_count();
     int64_t cap = 3072;
     if (cap > n_words / 256) cap = n_words / 256 > 16 ? n_words / 256 : 16;
+    // store-based rows (agent, plain) need ~4 workgroups per CU for their pair rate (131 019 rows: 256 workgroups 5.0e8
+    // pairs/s, 1024 1.09e9) and, with the in-order hand-out, hold the band there (+0.0002 at 1024 ... 2048 workgroups)
+    if (update_mode != kAtomic && cap < 4 * cus) cap = 4 * cus;
     if (cap > cus) cap -= cap % cus;
     return cap;
 }

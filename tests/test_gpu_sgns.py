@@ -492,8 +492,12 @@ def test_main_link_flow_with_user_edges(torch_cuda):
     emb = {int(u): vec[int(i)].cpu().numpy() for u, i in zip(users, ud.tolist())}
     want = augment_oracle.add_user_edge([int(u) for u in users], emb, "ratio", 0.02, 0.5)
     got = list(zip(users[s.cpu().numpy()].tolist(), users[d.cpu().numpy()].tolist()))
-    agree = sum(1 for a, b in zip(got, [(x[0], x[1]) for x in want]) if a == b) / max(len(want), 1)
-    assert len(got) == len(want) and agree > 0.999   # fp32 GEMM vs per-pair dot: only near-ties may swap
+    want_pairs = [(x[0], x[1]) for x in want]
+    agree = sum(1 for a, b in zip(got, want_pairs) if a == b) / max(len(want), 1)
+    same = len(set(got) & set(want_pairs)) / max(len(want), 1)
+    # fp32 GEMM vs per-pair dot: near-ties may swap places (the vectors come out of a racing training run, so how many
+    # there are differs from run to run: 0 ... 4 of 3 200) and, at the cut of a user's list, membership
+    assert len(got) == len(want) and same > 0.999 and agree > 0.995, (same, agree)
     print("user edges: %d added, AUC %.4f -> %.4f" % (res["edges_added"], res["roc"], res["roc_user"]))
 
 
