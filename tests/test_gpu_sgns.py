@@ -160,6 +160,46 @@ def test_walk_splits_train_the_same_pairs_and_stay_in_the_band(torch_cuda):
         ref.train_pass(corpus.walks, corpus.lens, sentences_base=0, sentences_total=1, walk_id_base=0, splits=81)
 
 
+def test_in_order_items_train_every_sentence_once(torch_cuda):
+    """Sentences are handed to the wavefronts through a device counter (n2v_sgns_train's work_counter) instead of a static
+    grid stride: every item exactly once — the pair count (a deterministic function of the corpus and the seeds) equals
+    the static stride's, at a grid far below and one far above the number of sentences per wave — and a single
+    wavefront, which trains the corpus strictly in order either way, leaves bit-identical tables."""
+    torch = torch_cuda
+    from n2v_hip import sgns
+    g, corpus, counts, te_d, neg_d, rounds, auc_cpu = _band_case("uniform")
+    walks, lens = corpus.walks[:6000].contiguous(), corpus.lens[:6000].contiguous()
+
+    def run(counter, blocks, n=None):
+        m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1)
+        m.build_vocab(counts=counts)
+        if not counter:
+            m.work_counter = None
+        w, l = (walks, lens) if n is None else (walks[:n].contiguous(), lens[:n].contiguous())
+        m.train_pass(w, l, sentences_base=0, sentences_total=walks.shape[0], walk_id_base=0, max_blocks=blocks)
+        torch.cuda.synchronize()
+        return m
+
+    want = run(False, 64).pairs_trained()
+    for blocks in (1, 7, 64, 3072):
+        assert run(True, blocks).pairs_trained() == want, blocks
+    a, b = run(True, 1, n=4), run(False, 1, n=4)       # 4 sentences on the 4 waves of one workgroup: one item per wave
+    assert a.pairs_trained() == b.pairs_trained()
+    one = torch.tensor([[int(x) for x in walks[0].tolist()]], dtype=torch.int32, device=walks.device)
+    ln = lens[:1].contiguous()
+    ms = []
+    for counter in (True, False):
+        m = sgns.SgnsModel(g.n_nodes, dim=128, window=10, negative=5, seed=1)
+        m.build_vocab(counts=counts)
+        if not counter:
+            m.work_counter = None
+        for rep in range(3):                               # the counter is reset by every launch
+            m.train_pass(one, ln, sentences_base=rep, sentences_total=3, walk_id_base=rep, max_blocks=1)
+        torch.cuda.synchronize()
+        ms.append(m)
+    assert torch.equal(ms[0].syn0, ms[1].syn0) and torch.equal(ms[0].syn1neg, ms[1].syn1neg)
+
+
 def test_parallel_negative_draws_train_the_same_bits(torch_cuda, monkeypatch):
     """The kernel draws all negatives of a centre in parallel (draw d of the centre = the walk's LCG advanced d times)
     instead of pair by pair (N2V_SGNS_PREDRAW=0).  One walk on one wavefront is a sequential, deterministic
