@@ -1,7 +1,7 @@
 """Comparator fixtures of the SGNS acceptance band (BASELINE.json: link-prediction AUC within +-0.002).
 
 CPU only, run in the build container (`python tests/golden/make_sgns_band.py [case ...]`; the 131 072-node cases take
-10 and 35 minutes on one core each, cases run in parallel processes).  For every case of tests/band_cases.py:
+17 and 63 minutes on one core each, the 400k-node case 3.8 h; cases run in parallel processes).  For every case of tests/band_cases.py:
 
   1. the C oracle (oracle/n2v_oracle.c — pinned bit for bit to the reference's src/node2vec.py by tests/golden/*.npz)
      walks the training graph with Philox uniforms, seed 1: the same walks the HIP kernel produces (the -m gpu tests

@@ -3,7 +3,8 @@ where the row-sharing mode matters, against COMMITTED comparator fixtures (run w
 
 tests/golden/sgns_band/*.json hold what the sequential comparator (oracle/sgns_oracle.c, one thread — gensim 3.2.0's
 published algorithm; parity unpinned, see its header) reaches on the C oracle's Philox walks of each graph; they are
-made on CPU by tests/golden/make_sgns_band.py (35 minutes for the largest case, which is why they are fixtures).  A
+made on CPU by tests/golden/make_sgns_band.py (an hour for the 131k cases, 3.8 h for the 400k one, which is why they are
+fixtures).  A
 test rebuilds the same graph, walks it on the GPU, checks that the walks ARE the fixture's walks (hash of the int32
 array — the walk kernel is bit-identical to the C oracle), trains with the HIP kernel at the DEFAULT grid and scores
 the same held-out pairs (src/main_link.py:173-204,525-563)."""
@@ -62,7 +63,7 @@ def test_single_gpu_auc_within_band_of_sequential_comparator(name, mode, resolve
                        update_mode=mode, allow_out_of_band=(mode == "agent"))      # 53 rows short of the `auto` rule
     m.build_vocab(counts=counts)
     assert m.update_mode_name == resolved
-    sgns.train(m, corpus.walks, corpus.lens, epochs=1)          # default grid (3 072 workgroups, capped by the table size)
+    sgns.train(m, corpus.walks, corpus.lens, epochs=1)          # default grid (n2v_sgns_default_blocks)
     torch.cuda.synchronize()
     auc, ap = linkpred.get_roc_score(m.vectors(), te_d, neg_d)
     print("%s %s(%s): AUC %.5f vs sequential comparator %.5f (%+.5f) | AP %.5f vs %.5f | pairs %d vs %d" % (
