@@ -287,6 +287,9 @@ __device__ __forceinline__ int64_t next_item(unsigned long long* counter, int la
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 template <int VPL, int G, int MODE>
+// 8 waves per SIMD: the default allocation (106 SGPRs) stops at 7; capped, the kernel fits 78 SGPRs / 61 VGPRs without
+// spilling and the agent-row pass gains 1.4 % (10^6-row probe: 9.61 -> 9.74e8 pairs/s)
+__attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ void __launch_bounds__(256) sgns_kernel(SgnsArgs a_in) {
     SgnsArgs a = a_in;
     resolve_span(a);
