@@ -847,7 +847,7 @@ int sgns_launch(const char* who, const int32_t* walks, const int32_t* lens, int6
     if (shmem > 64 * 1024) return n2v::fail(N2V_ERR_INVALID, "n2v_sgns_train: walk_stride %d too long", (int)walk_stride);
     int64_t blocks = (n_walks * walk_splits + 3) / 4;
     // default grid: 256 CUs x 12 workgroups of 4 waves (measured on C3: 2048 blocks 6.9e8 pairs/s, 3072 8.2e8, 4096
-    // 8.0e8, 6144 8.3e8; at today's 63 VGPRs 7 of the 12 are resident at a time and the others follow as slots free up —
+    // 8.0e8, 6144 8.3e8; at 8 waves per SIMD 8 of the 12 are resident at a time and the others follow as slots free up —
     // harmless with the in-order hand-out, and the reason the static stride lost the band at large grids: a workgroup
     // that starts late trains its whole strided share of the corpus after everybody else) — but
     //  (1) never more than one wavefront per 64 vocabulary rows: the racing waves read each other's rows stale, and
